@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — rendered frames/s of the generator forward (+ blend) at 512x512.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one
+512x512 frame (B=1, fp32) through Generator.forward plus the driver's blend,
+device-resident (BASELINE.json configs[1]).  For N>1 the driver launches one
+rank per GPU (torch.distributed.run); rank 0 builds the weights, they reach the
+other ranks through ONE RCCL broadcast of the folded blob, and every rank then
+renders its own frames with no further communication (weak scaling).
+
+Printed JSON (rank 0): metric/value/unit as the contract asks, plus
+  roofline     dominant kernel class (the MFMA implicit-GEMM convolutions):
+               algorithmic FLOPs per forward / device time of those launches,
+               measured with HIP events on the launch stream in a separate
+               profiling pass, against the dense fp32 MFMA peak
+  cpu_baseline the CPU oracle (PyTorch fp32 restatement of the reference)
+               timed on this box's host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch                                    # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md, dense fp32 matrix
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+
+    import render_in_between_amd as rib
+    from render_in_between_amd import synth, distributed as ribdist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        ribdist.init_process_group()
+
+    cfg = rib.hsm_gen_config()
+    spec = rib.GenSpec.from_cfg(cfg)
+    H = W = args.size
+    B = args.batch
+    G = rib.Generator(cfg, device=dev).eval()
+    sd = None
+    t_bcast_ms = 0.0
+    if rank == 0:
+        sd = synth.make_state_dict(spec, 0)
+        G.load_state_dict(sd)
+    if world > 1:
+        t_bcast_ms = ribdist.broadcast_weights(G, src=0)
+
+    # per-rank synthetic inputs (rank r renders its own frames)
+    label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 1000 * rank)]
+
+    def step():
+        img, mask = G(label, None, fake, prev)
+        return G.blend(img, mask, fake)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    fps = world * B * args.steps / dt
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel class: profiling pass (not in the timed region) ----
+    flops = G.forward_flops(B, H, W)
+    G.profile_begin()
+    nprof = 5
+    for _ in range(nprof):
+        step()
+    prof = G.profile_collect()
+    conv_ms = prof["igemm"]["ms"] / nprof
+    conv_tflops = flops["igemm"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    spade_ms = prof["spade"]["ms"] / nprof
+    classes = {k: {"launches_per_step": v["launches"] / nprof, "ms_per_step": v["ms"] / nprof} for k, v in prof.items()}
+    roofline = {
+        "bound": "mfma", "kernel": "k_igemm (fp32 MFMA implicit-GEMM convolution, %d launches/step)" % int(prof["igemm"]["launches"] / nprof),
+        "achieved": conv_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": conv_tflops / PEAK_F32_MFMA_TFLOPS,
+        "avg_launch_us": conv_ms * 1e3 / max(1.0, prof["igemm"]["launches"] / nprof),
+        "algorithmic_gflop_per_step": flops["igemm"] / 1e9,
+        "traffic": None,
+        "classes": classes,
+        "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
+        "whole_step_frac_of_mfma_roof": (sum(flops.values()) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
+    }
+
+    # ---- parity on the bench inputs + CPU baseline (oracle timed on the host cores) ----
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle import generator_ref
+        R = generator_ref.RefGenerator(spec, sd)
+        torch.set_num_threads(os.cpu_count() or 1)
+        lc, fc, pc = label.cpu(), fake.cpu(), prev.cpu()
+        oimg, omask = R(lc, None, fc, pc)                       # warm-up + parity reference
+        img, mask = G(label, None, fake, prev)
+        parity = {"max_abs_img": float((img.cpu() - oimg).abs().max()),
+                  "max_abs_mask": float((mask.cpu() - omask).abs().max()), "tolerance": 1e-3}
+        ts = []
+        for _ in range(args.cpu_frames):
+            t1 = time.perf_counter()
+            oi, om = R(lc, None, fc, pc)
+            generator_ref.blend(oi, om, fc)
+            ts.append(time.perf_counter() - t1)
+        med = sorted(ts)[len(ts) // 2]
+        cpu = {"value": B / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "%d forward+blend passes of the same %dx%d B=%d fp32 workload through the CPU oracle "
+                         "(PyTorch restatement validated against the imported reference), median" % (args.cpu_frames, H, W, B)}
+
+    line = {
+        "metric": "rendered frames/sec at 512x512 (generator forward + blend, device-resident)",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%d single-frame generator fwd + blend, batch=%d, fp32, seed-defined random-init "
+                               "HSM.yaml generator (spectral-norm vectors power-iterated)" % (H, W, B),
+                   "frames_per_step_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), one RCCL weight broadcast" % world,
+                   "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

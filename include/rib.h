@@ -1,0 +1,150 @@
+/*
+ * rib.h — C ABI of the MI355X-native pose-guided generator ("Render-In-Between" hot path).
+ *
+ * The reference (azuxmioy/Render-In-Between) is pure Python and has no FFI layer: its boundary for
+ * this path is the Python object protocol between the sequence driver and the generator module
+ * (Pose_Guided_Neural_Rendering, abbreviated PGNR below).  Every entry point cites the reference
+ * interface it replaces.  All functions return 0 on success or a negative rib_status; no C++
+ * exception crosses this boundary.  rib_last_error() gives the message of the last failure.
+ *
+ * Ownership: the caller owns every tensor and the workspace; a handle owns only the weight blob
+ * and its launch plans.  A handle is bound to one device, is single-stream and not re-entrant
+ * (one handle per GPU / process).  All kernels are enqueued on the caller's stream; no entry point
+ * synchronises the device except rib_finalize_weights(), rib_read_tap() and rib_profile_collect().
+ *
+ * Tensors at the boundary are dense fp32 NCHW on the handle's device, exactly what the reference
+ * generator takes and returns (PGNR/models/evaluator.py:250-255).
+ */
+#ifndef RIB_H
+#define RIB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rib_handle rib_handle;
+
+typedef enum {
+  RIB_OK = 0,
+  RIB_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+  RIB_ERR_UNSUPPORTED = -2,  /* generator variant the path does not implement */
+  RIB_ERR_STATE = -3,        /* e.g. forward before weights are loaded */
+  RIB_ERR_MISSING = -4,      /* a required checkpoint tensor was never set */
+  RIB_ERR_HIP = -5,          /* a HIP runtime call failed */
+  RIB_ERR_WORKSPACE = -6     /* workspace too small */
+} rib_status;
+
+/* Resolved hyper-parameters of Generator(gen_cfg): the keys PGNR/models/generator.py:46-65,
+ * 317-324, 431-440 reads from configs/HSM.yaml:35-67 (after getattr defaults). */
+typedef struct {
+  int32_t label_nc;          /* gen.input_label_nc   (22) */
+  int32_t image_nc;          /* gen.input_image_nc   (3)  */
+  int32_t num_filters;       /* gen.num_filters      (16) */
+  int32_t max_num_filters;   /* gen.max_num_filters  (512) */
+  int32_t num_layers;        /* gen.num_layers       (6)  */
+  int32_t num_down_img;      /* gen.num_downsamples_img, default 4 (generator.py:50) */
+  int32_t emb_filters;       /* gen.embed.num_filters      (64)  */
+  int32_t emb_max_filters;   /* gen.embed.max_num_filters  (512) */
+  int32_t emb_down;          /* gen.embed.num_downsamples  (4)   */
+  int32_t mask_filters;      /* gen.mask.num_filters       (32)  */
+  int32_t mask_max_filters;  /* gen.mask.max_num_filters   (512) */
+  int32_t mask_down;         /* gen.mask.num_downsamples   (3)   */
+  int32_t mask_res_blocks;   /* gen.mask.num_res_blocks    (4)   */
+} rib_config;
+
+/* ---- construction: replaces Generator(cfg.gen).to(device) (PGNR/models/trainer.py:61) ---- */
+int rib_create(const rib_config* cfg, int device, rib_handle** out);
+void rib_destroy(rib_handle* h);
+/* h may be NULL: message of the last failed rib_create on this thread. */
+const char* rib_last_error(const rib_handle* h);
+
+/* ---- weights: replaces load_state_dict(net_G, path) (PGNR/utils/utils.py:107-119) ----
+ * The handle speaks the reference checkpoint's vocabulary: the caller hands over the raw
+ * state-dict tensors by their reference names ('down_0.conv_block_0.layers.conv.weight_orig',
+ * '...weight_u', '...layers.norm.mlps.0.0.layers.conv.weight', ...).  rib_finalize_weights()
+ * folds the eval-mode spectral norm  W = W_orig / (u . W_mat v)  (hook of
+ * PGNR/models/layers/weight_norm.py:84-85), re-lays the filters out for the kernels and uploads
+ * one contiguous device blob.  Tensors of modules the forward never calls (label_embedding.*,
+ * conv_mask.*) are accepted and ignored; unknown names are an error (strict load). */
+int rib_num_tensors(const rib_handle* h);
+int rib_tensor_info(const rib_handle* h, int idx, const char** name, int* ndim, int64_t dims[4],
+                    int* used);
+int rib_set_tensor(rib_handle* h, const char* name, const float* host_data, int ndim,
+                   const int64_t* dims);
+int rib_finalize_weights(rib_handle* h);
+/* The folded device blob, for the one RCCL broadcast of the multi-GPU path: rank 0 finalizes and
+ * exports the blob into a caller-owned device buffer, the caller broadcasts that buffer
+ * (torch.distributed / RCCL over xGMI), every other rank imports it.  Both copies are
+ * device-to-device and asynchronous on the given stream. */
+size_t rib_weights_bytes(const rib_handle* h);
+int rib_export_weights(rib_handle* h, void* dst_device, size_t bytes, void* hip_stream);
+int rib_import_weights(rib_handle* h, const void* src_device, size_t bytes, void* hip_stream);
+
+/* ---- forward: replaces  img, mask = net_G(label, label_prev, img_fake, img_prev)
+ *      (PGNR/models/generator.py:181-234; call site PGNR/models/evaluator.py:255) ----
+ * label [B,label_nc,H,W], img_fake/img_prev [B,image_nc,H,W] -> img [B,image_nc,H,W] (tanh),
+ * mask [B,1,H,W] (sigmoid).  label_prev is dead in the reference and has no
+ * parameter.  H and W must be multiples of 2^max(num_down_img, mask_down). */
+size_t rib_workspace_bytes(rib_handle* h, int B, int H, int W);
+int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
+                const float* img_prev, float* img, float* mask, void* workspace,
+                size_t workspace_bytes, void* hip_stream);
+
+/* ---- autoregressive segment: replaces the inference loop body of
+ *      Evaluator.evaluate_from_folder (PGNR/models/evaluator.py:238-262) ----
+ * prev <- key_frame; for t in 0..T-1:
+ *   img_t, mask_t = G(labels[t], ., dains[t], prev); fuse_t = img_t*mask_t + dains[t]*(1-mask_t);
+ *   prev <- fuse_t.
+ * labels [T,B,label_nc,H,W], dains [T,B,image_nc,H,W], key_frame [B,image_nc,H,W];
+ * outputs imgs/fuses [T,B,image_nc,H,W], masks [T,B,1,H,W]; imgs and masks may be NULL. */
+int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
+              const float* labels, const float* dains, float* imgs, float* masks, float* fuses,
+              void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* fuse = img*mask + dain*(1-mask) (PGNR/models/evaluator.py:256-258); n = B*H*W pixels. */
+int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const float* mask,
+              const float* dain, float* fuse, void* hip_stream);
+/* uint8 HWC frame = uint8(clip(x*0.5+0.5,0,1)*255), truncating (PGNR/utils/utils.py:129-142). */
+int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img_nchw,
+                 uint8_t* out_nhwc, void* hip_stream);
+/* Extension op named by the north star but absent from the reference: bilinear
+ * flow-grid warp, semantics of torch.nn.functional.grid_sample(img, base+flow*2/(size-1),
+ * 'bilinear', padding_mode='border', align_corners=True).  flow [B,2,H,W] in pixels (x,y). */
+int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const float* flow,
+             float* out, void* hip_stream);
+
+/* ---- introspection for parity tests (no reference counterpart) ----
+ * After a rib_forward on `workspace`, intermediate activations can be read back as NCHW. */
+int rib_num_taps(rib_handle* h, int B, int H, int W);
+int rib_tap_info(rib_handle* h, int B, int H, int W, int idx, const char** name, int* C, int* th,
+                 int* tw);
+int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* workspace,
+                 float* dst_nchw_device, void* hip_stream);
+
+/* ---- measurement: per-kernel-class device time with HIP events on the caller's stream ----
+ * rib_profile_begin() makes subsequent rib_forward calls bracket every launch with events
+ * (slower; never enable inside a timed region).  rib_profile_collect() synchronises and returns,
+ * per class, the number of launches and total milliseconds since begin. */
+enum { RIB_KC_IGEMM = 0, RIB_KC_SPADE = 1, RIB_KC_STATS = 2, RIB_KC_POOL = 3, RIB_KC_ELTWISE = 4,
+       RIB_KC_PACK = 5, RIB_KC_COUNT = 6 };
+int rib_profile_begin(rib_handle* h);
+int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms[RIB_KC_COUNT]);
+/* Algorithmic FLOPs (2*MAC) one rib_forward spends in class RIB_KC_IGEMM / RIB_KC_SPADE. */
+int rib_forward_flops(rib_handle* h, int B, int H, int W, double flops[RIB_KC_COUNT]);
+int rib_num_launches(rib_handle* h, int B, int H, int W);
+
+/* ---- host-only debugging (CPU tests): rib_create(cfg, device = -1, ..) builds a handle that owns
+ * no device memory; it supports the tensor inventory, rib_set_tensor / rib_finalize_weights (the
+ * folded blob stays on the host), plans (workspace size, launch list, FLOPs) and these readers,
+ * which undo the filter re-layout so the fold can be compared with the oracle. ---- */
+int rib_debug_conv_weight(rib_handle* h, const char* conv_name, float* w_oihw, float* bias);
+int rib_debug_spade_weight(rib_handle* h, const char* conv_name, float* w_2c_by_cond, float* bias_2c);
+int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIB_H */

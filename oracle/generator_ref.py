@@ -89,10 +89,12 @@ def spade_res_block(sd, name, x, cond, taps=None):
     return xs + dx
 
 
-def conv_in_lrelu(sd, name, x, stride=1, act=True):
+def conv_in_lrelu(sd, name, x, stride=1, act=True, taps=None, tapname=None):
     """Conv2dBlock(order='CNA') with InstanceNorm2d(affine=True) (generator.py:442-459)."""
     w, b = conv_weight(sd, name)
     y = F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
+    if taps is not None and tapname:
+        taps[tapname] = y
     y = instance_norm(y, sd[name + ".layers.norm.weight"], sd[name + ".layers.norm.bias"])
     return lrelu(y) if act else y
 
@@ -129,18 +131,23 @@ class RefGenerator:
         sd, m = self.sd, "flow_network_temp"
         a, b = label, img9
         for i in range(self.spec.mask_down + 1):
-            a = conv_in_lrelu(sd, "%s.down_lbl.%d" % (m, i), a, stride=1 if i == 0 else 2)
-            b = conv_in_lrelu(sd, "%s.down_img.%d" % (m, i), b, stride=1 if i == 0 else 2)
+            a = conv_in_lrelu(sd, "%s.down_lbl.%d" % (m, i), a, stride=1 if i == 0 else 2,
+                              taps=taps, tapname="mask.lbl_%d.raw" % i)
+            b = conv_in_lrelu(sd, "%s.down_img.%d" % (m, i), b, stride=1 if i == 0 else 2,
+                              taps=taps, tapname="mask.img_%d.raw" % i)
         r = torch.cat([a, b], dim=1)
         if taps is not None:
             taps["mask.cat"] = r
+            taps["mask.cat.raw"] = torch.cat([taps.pop("mask.lbl_%d.raw" % self.spec.mask_down),
+                                              taps.pop("mask.img_%d.raw" % self.spec.mask_down)], dim=1)
         for i in range(self.spec.mask_res_blocks):
             r = mask_res_block(sd, "%s.res_flow.%d" % (m, i), r)
             if taps is not None:
                 taps["mask.res_%d" % i] = r
         for j in range(self.spec.mask_down):
             r = F.interpolate(r, scale_factor=2, mode="nearest")       # nn.Upsample(scale_factor=2)
-            r = conv_in_lrelu(sd, "%s.up_flow.%d" % (m, 2 * j + 1), r)
+            r = conv_in_lrelu(sd, "%s.up_flow.%d" % (m, 2 * j + 1), r, taps=taps,
+                              tapname="mask.up_%d.raw" % j)
             if taps is not None:
                 taps["mask.up_%d" % j] = r
         w, bb = conv_weight(sd, m + ".conv_mask.0")

@@ -1,0 +1,88 @@
+"""ctypes binding of the C ABI declared in include/rib.h (librib.so).
+
+There is deliberately no fallback: if the library is missing this raises, and
+every compute entry point needs a real GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librib.so")
+
+KC_NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
+
+
+class RibConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "label_nc", "image_nc", "num_filters", "max_num_filters", "num_layers", "num_down_img",
+        "emb_filters", "emb_max_filters", "emb_down", "mask_filters", "mask_max_filters",
+        "mask_down", "mask_res_blocks")]
+
+
+class RibError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rib error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); must cover every symbol of include/rib.h
+SIGNATURES = {
+    "rib_create": (C.c_int, [C.POINTER(RibConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "rib_destroy": (None, [C.c_void_p]),
+    "rib_last_error": (C.c_char_p, [C.c_void_p]),
+    "rib_num_tensors": (C.c_int, [C.c_void_p]),
+    "rib_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "rib_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "rib_finalize_weights": (C.c_int, [C.c_void_p]),
+    "rib_weights_bytes": (C.c_size_t, [C.c_void_p]),
+    "rib_export_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rib_import_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rib_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rib_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+                    + [C.c_size_t, C.c_void_p]),
+    "rib_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+                  + [C.c_size_t, C.c_void_p]),
+    "rib_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "rib_quantise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3),
+    "rib_warp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "rib_num_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rib_tap_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rib_read_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "rib_profile_begin": (C.c_int, [C.c_void_p]),
+    "rib_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "rib_forward_flops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "rib_num_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rib_debug_conv_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "rib_debug_spade_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "rib_debug_launch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+}
+
+
+def lib():
+    """Load librib.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "native library %s is missing: build it with "
+                "`python render-in-between_amd/csrc/build.py` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = lib().rib_last_error(handle)
+        raise RibError(rc, msg.decode() if msg else "?")

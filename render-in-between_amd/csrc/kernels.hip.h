@@ -1,0 +1,571 @@
+// kernels.hip.h — hand-written CDNA4 (gfx950) kernels of the generator forward.
+//
+// Data layout: every activation is NHWC fp32 in HBM (channel-contiguous: 16-byte coalesced
+// loads along C, concatenation = channel-offset writes, K of the implicit GEMM contiguous).
+// The dominant kernel, k_igemm, is an implicit-GEMM convolution on the exact-fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32): M = output pixels of one spatial tile, N = output channels,
+// K = taps x input channels.  The input halo tile is staged ONCE per channel chunk into LDS
+// (with the fused InstanceNorm-affine + LeakyReLU prologue applied on the way in), and the
+// taps read shifted windows of it; filter slices are double-buffered in LDS.
+//
+// Reference semantics restated by these kernels (PGNR = Pose_Guided_Neural_Rendering):
+//   conv / zero padding / stride 2      PGNR/models/layers/conv.py:93-104, generator.py:55,344-348
+//   InstanceNorm (biased var, eps 1e-5) PGNR/models/layers/activation_norm.py:399-402
+//   SPADE  IN(x)*(1+gamma)+beta         PGNR/models/layers/activation_norm.py:211-234
+//   LeakyReLU(0.2), sigmoid, tanh       PGNR/models/layers/nonlinearity.py:21-28, generator.py:228
+//   nearest x2 upsample (src = dst>>1)  PGNR/models/generator.py:128,248-249,480
+//   AvgPool2d(3,2,1) divisor 9          PGNR/models/generator.py:127
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rib {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+__device__ __forceinline__ float4 lrelu4(float4 v) {
+  return make_float4(lrelu(v.x), lrelu(v.y), lrelu(v.z), lrelu(v.w));
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_LRELU) return lrelu(v);
+  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_igemm parameters.  All pointers are device pointers; tensors NHWC with an explicit channel
+// stride (xC, yC, ...) so that channel slices of wider buffers can be read / written in place.
+// ---------------------------------------------------------------------------------------------
+struct IgemmParams {
+  // A operand: input activation (conv) or SPADE condition map
+  const float* x;
+  int Hin, Win, xC;      // stored spatial size and channel stride of x
+  int Cin;               // channels consumed (multiple of BK, <= xC)
+  // prologue on x: v = lrelu?(v*scale[n][c] + shift[n][c]); zero padding applied AFTER it
+  const float* pro_scale;  // [B][pro_ld] or nullptr
+  const float* pro_shift;
+  int pro_ld;
+  int pro_lrelu;
+  // B operand: filters [CoutPad][taps][Cin] (Cin contiguous), bias [CoutPad]
+  const float* w;
+  const float* bias;
+  int CoutPad;           // rows present in w / bias (multiple of 32)
+  // output
+  int Hout, Wout;
+  int tilesX, tilesY;
+  // --- conv epilogue ---
+  float* y;              // [B][Hout][Wout][yC], written at channel offset yoff
+  int yC, yoff, Cout;    // Cout = valid output channels
+  int act;
+  const float* res;      // residual added before act/store, [B][Hout][Wout][resC] or nullptr
+  int resC;
+  float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
+  float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
+  // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
+  const float* xm;       // tensor being normalised, [B][Hm][Wm][xmC]
+  int xmC, xm_ups;       // xm_ups: xm is stored at half resolution (nearest x2 upsample on read)
+  const float* m_scale;  // [B][m_ld] = rstd          (IN affine=False)
+  const float* m_shift;  // [B][m_ld] = -mean*rstd
+  int m_ld;
+  int C;                 // channels of xm
+  int nsets;             // 1 or 2 modulations of the same xm (conv_block_0 + conv_block_s)
+  float* ys0; float* ys1;  // outputs [B][Hout][Wout][C]
+  int act0, act1;
+};
+
+// Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
+// MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
+// WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS>
+struct IgemmGeom {
+  static constexpr int FRH = 32 / FRW;
+  static constexpr int TH = FRH * MF * WM;
+  static constexpr int TW = FRW;
+  static constexpr int IH = UPS ? (TH / 2 + 2) : ((TH - 1) * STRIDE + KS);
+  static constexpr int IW = UPS ? (TW / 2 + 2) : ((TW - 1) * STRIDE + KS);
+  static constexpr int CK = BK + 4;            // padded LDS row: conflict-free ds_read_b128
+  static constexpr int BN = 32 * NF * WN;
+  static constexpr int SA = IH * IW * CK;      // floats
+  static constexpr int SB = BN * CK;           // floats, one of two buffers
+  static constexpr int NB4 = (BN * BK / 4 + 255) / 256;   // float4 filter loads per thread per tap
+  static constexpr int SRED = WM * BN * 2;
+  static constexpr int SMEM = SA + 2 * SB > SRED ? SA + 2 * SB : SRED;
+  static constexpr int TAPS = KS * KS;
+};
+
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE>
+__global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS> G;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(!SPADE || (NF % 2 == 0), "SPADE needs gamma/beta fragment pairs");
+  static_assert(!UPS || (STRIDE == 1 && KS == 3), "upsample gather only for 3x3 stride 1");
+  __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+  float* sA = smem;
+  float* sB = smem + G::SA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int n = blockIdx.z;
+  const int tile = blockIdx.x;
+  const int ty0 = (tile / p.tilesX) * G::TH;
+  const int tx0 = (tile % p.tilesX) * G::TW;
+  const int n0 = blockIdx.y * G::BN;
+
+  // input-tile origin in stored-input coordinates
+  int iy0, ix0;
+  if (UPS) { iy0 = ty0 / 2 - 1; ix0 = tx0 / 2 - 1; }
+  else { iy0 = ty0 * STRIDE - (KS / 2); ix0 = tx0 * STRIDE - (KS / 2); }
+
+  // per-lane tile pixel of each M fragment
+  int fy[MF], fx;
+  fx = li % FRW;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) fy[mf] = (wm * MF + mf) * G::FRH + li / FRW;
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+  const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
+  const int wrow = G::TAPS * p.Cin;   // floats per filter row
+
+  // filter prefetch registers
+  float4 breg[G::NB4];
+  auto loadB = [&](int kc, int tap) {
+#pragma unroll
+    for (int i = 0; i < G::NB4; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < G::BN && n0 + row < p.CoutPad)
+        v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * 4);
+      breg[i] = v;
+    }
+  };
+  auto storeB = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < G::NB4; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+      if (row < G::BN)
+        *reinterpret_cast<float4*>(sB + buf * G::SB + row * G::CK + c4 * 4) = breg[i];
+    }
+  };
+
+  loadB(0, 0);
+  for (int kc = 0; kc < p.Cin; kc += BK) {
+    __syncthreads();   // every wave is done reading sA / sB of the previous chunk
+    // ---- stage the input halo tile for channels [kc, kc+BK) with the fused prologue ----
+    {
+      constexpr int total4 = G::IH * G::IW * (BK / 4);
+      for (int idx = tid; idx < total4; idx += 256) {
+        const int c4 = idx % (BK / 4);
+        const int pix = idx / (BK / 4);
+        const int ly = pix / G::IW, lx = pix % G::IW;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+          v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.Win + ix) * p.xC + kc + c4 * 4);
+          if (p.pro_scale) {
+            const float4 s = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + c4 * 4);
+            const float4 t = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + c4 * 4);
+            v = make_float4(v.x * s.x + t.x, v.y * s.y + t.y, v.z * s.z + t.z, v.w * s.w + t.w);
+          }
+          if (p.pro_lrelu) v = lrelu4(v);
+        }
+        *reinterpret_cast<float4*>(sA + pix * G::CK + c4 * 4) = v;
+      }
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < G::TAPS; ++tap) {
+      const int buf = tap & 1;
+      storeB(buf);
+      {  // prefetch the next filter slice while this tap computes
+        int ntap = tap + 1, nkc = kc;
+        if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
+        if (nkc < p.Cin) loadB(nkc, ntap);
+      }
+      __syncthreads();
+      const int dy = tap / KS, dx = tap % KS;
+      int aoff[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        int r, c;
+        if (UPS) { r = ((fy[mf] + dy - 1) >> 1) + 1; c = ((fx + dx - 1) >> 1) + 1; }
+        else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
+        aoff[mf] = (r * G::IW + c) * G::CK + lh * 4;
+      }
+      const float* sBb = sB + buf * G::SB + (wn * NF * 32 + li) * G::CK + lh * 4;
+#pragma unroll
+      for (int kb = 0; kb < BK / 8; ++kb) {
+        float4 a[MF], b[NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + kb * 8);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ------------------------------------ epilogue ------------------------------------
+  // accumulator element r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5)  (pixel), col = l&31 (channel)
+  if (!SPADE) {
+    float s1[NF], s2[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int col = n0 + (wn * NF + nf) * 32 + li;
+      const bool cvalid = col < p.Cout;
+      const float bv = (col < p.CoutPad) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          const int ox = tx0 + row % FRW;
+          if (cvalid && oy < p.Hout && ox < p.Wout) {
+            const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+            float v = acc[mf][nf][r] + bv;
+            if (p.res) v += p.res[pix * p.resC + col];
+            v = apply_act(v, p.act);
+            p.y[pix * p.yC + p.yoff + col] = v;
+            if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = v;
+            s1[nf] += v;
+            s2[nf] += v * v;
+          }
+        }
+      }
+    }
+    if (p.stat_part) {   // deterministic per-tile partial sums for the following InstanceNorm
+      __syncthreads();   // all waves finished the main loop: smem can be reused
+      float* red = smem;   // [WM][BN][2]
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        float a1 = s1[nf] + __shfl_xor(s1[nf], 32);
+        float a2 = s2[nf] + __shfl_xor(s2[nf], 32);
+        if (lh == 0) {
+          const int c = (wn * NF + nf) * 32 + li;
+          red[(wm * G::BN + c) * 2 + 0] = a1;
+          red[(wm * G::BN + c) * 2 + 1] = a2;
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < G::BN; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) { a1 += red[(m * G::BN + c) * 2]; a2 += red[(m * G::BN + c) * 2 + 1]; }
+        const int col = n0 + c;
+        if (col < p.CoutPad) {
+          float* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
+          dst[col] = a1;
+          dst[p.CoutPad + col] = a2;
+        }
+      }
+    }
+  } else {
+    // fragment pair (2q, 2q+1) = (gamma, beta) of 32 consecutive virtual channels
+#pragma unroll
+    for (int q = 0; q < NF / 2; ++q) {
+      const int colg = n0 + (wn * NF + 2 * q) * 32 + li;       // gamma column in w / bias
+      const int v = (n0 / 2) + (wn * NF / 2 + q) * 32 + li;    // virtual channel
+      const bool vvalid = v < p.nsets * p.C;
+      const int set = (vvalid && v >= p.C) ? 1 : 0;
+      const int c = v - set * p.C;
+      float bg = 0.f, bb = 0.f, sc = 0.f, sh = 0.f;
+      if (vvalid) {
+        bg = p.bias[colg]; bb = p.bias[colg + 32];
+        sc = p.m_scale[(size_t)n * p.m_ld + c]; sh = p.m_shift[(size_t)n * p.m_ld + c];
+      }
+      float* yout = set ? p.ys1 : p.ys0;
+      const int act = set ? p.act1 : p.act0;
+      const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          const int ox = tx0 + row % FRW;
+          if (vvalid && oy < p.Hout && ox < p.Wout) {
+            const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+            const float xv = p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c];
+            const float gamma = acc[mf][2 * q][r] + bg;
+            const float beta = acc[mf][2 * q + 1][r] + bb;
+            float o = (xv * sc + sh) * (1.f + gamma) + beta;
+            o = apply_act(o, act);
+            yout[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stats_finalize: per-tile partial sums -> (scale, shift) of the InstanceNorm that follows.
+//   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
+//   scale = rstd*gamma, shift = beta - mean*scale   (gamma=1, beta=0 when affine is absent)
+// Tiles are summed in a fixed order in fp64: deterministic and free of fp32 cancellation.
+// grid (Cs/32, B), block 256 = 32 channels x 8 tile slices.
+// ---------------------------------------------------------------------------------------------
+struct FinalizeParams {
+  const float* part;   // [B][tiles][2][Cs]
+  int tiles, Cs, C;    // C valid channels
+  const float* gamma;  // [C] or nullptr
+  const float* beta;
+  float* scale;        // [B][ld] at channel offset off
+  float* shift;
+  int ld, off;
+  float inv_count;     // 1 / (H*W)
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void k_stats_finalize(const FinalizeParams p) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int n = blockIdx.y;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < p.Cs) {
+    const float* base = p.part + (size_t)n * p.tiles * 2 * p.Cs;
+    for (int t = sl; t < p.tiles; t += 8) {
+      a1 += (double)base[(size_t)t * 2 * p.Cs + c];
+      a2 += (double)base[(size_t)t * 2 * p.Cs + p.Cs + c];
+    }
+  }
+  red[0][sl][cl] = a1;
+  red[1][sl][cl] = a2;
+  __syncthreads();
+  if (sl == 0 && c < p.C) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    const double mean = s1 * (double)p.inv_count;
+    double var = s2 * (double)p.inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float g = p.gamma ? p.gamma[c] : 1.f;
+    const float b = p.beta ? p.beta[c] : 0.f;
+    const float sc = rstd * g;
+    p.scale[(size_t)n * p.ld + p.off + c] = sc;
+    p.shift[(size_t)n * p.ld + p.off + c] = b - (float)mean * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_avgpool: AvgPool2d(3, stride 2, pad 1), divisor always 9, NHWC; also emits the per-block
+// partial sums of its OUTPUT (the next block's SPADE normalises the pooled tensor).
+// grid (blocks, B); each block covers PPB = 256/(C/4) * 4 output pixels, thread = (pixel slot, c4).
+// ---------------------------------------------------------------------------------------------
+struct PoolParams {
+  const float* x; float* y;
+  int H, W, C;          // input size; output H/2 x W/2
+  float* stat_part;     // [B][blocks][2][C]
+  int blocks;
+};
+
+__global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
+  __shared__ __attribute__((aligned(16))) float red[2][256][4];
+  const int c4n = p.C / 4;
+  const int slots = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
+  const int Ho = p.H / 2, Wo = p.W / 2;
+  const int n = blockIdx.y;
+  const int npix = Ho * Wo;
+  const int ppb = slots * 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  const float* xn = p.x + (size_t)n * p.H * p.W * p.C;
+  for (int k = 0; k < 4; ++k) {
+    const int pix = blockIdx.x * ppb + k * slots + slot;
+    if (pix < npix && slot < slots) {
+      const int oy = pix / Wo, ox = pix % Wo;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int ix = ox * 2 - 1 + dx;
+          if (ix < 0 || ix >= p.W) continue;
+          const float4 v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.W + ix) * p.C + c4 * 4);
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+      }
+      const float inv9 = 1.f / 9.f;
+      a.x *= inv9; a.y *= inv9; a.z *= inv9; a.w *= inv9;
+      *reinterpret_cast<float4*>(p.y + ((size_t)n * npix + pix) * p.C + c4 * 4) = a;
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][threadIdx.x][0]) = s1;
+  *reinterpret_cast<float4*>(&red[1][threadIdx.x][0]) = s2;
+  __syncthreads();
+  // thread t < C sums channel t over the pixel slots (fixed order)
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    const int g = c / 4, e = c % 4;
+    float a1 = 0.f, a2 = 0.f;
+    for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
+    float* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.C;
+    dst[c] = a1;
+    dst[p.C + c] = a2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_in_add: mask-network residual join (Res2dBlock 'CNACN', PGNR/models/generator.py:465-476):
+//   out = IN_affine(t1) + (ts ? IN_affine(ts) : xres)      float4 over [B][HW][C]
+// ---------------------------------------------------------------------------------------------
+struct InAddParams {
+  const float* t1; const float* sc1; const float* sh1;
+  const float* ts; const float* scs; const float* shs;   // ts may be nullptr
+  const float* xres;                                      // used when ts == nullptr
+  float* out;
+  int C, HW;
+  int ld;   // leading dim of the scale/shift arrays
+};
+
+__global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
+  const int c4n = p.C / 4;
+  const size_t total = (size_t)p.HW * c4n;
+  const int n = blockIdx.y;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    const size_t e = ((size_t)n * p.HW) * p.C + i * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p.t1 + e);
+    const float4 s = *reinterpret_cast<const float4*>(p.sc1 + (size_t)n * p.ld + c4 * 4);
+    const float4 t = *reinterpret_cast<const float4*>(p.sh1 + (size_t)n * p.ld + c4 * 4);
+    float4 o = make_float4(a.x * s.x + t.x, a.y * s.y + t.y, a.z * s.z + t.z, a.w * s.w + t.w);
+    if (p.ts) {
+      const float4 b = *reinterpret_cast<const float4*>(p.ts + e);
+      const float4 s2 = *reinterpret_cast<const float4*>(p.scs + (size_t)n * p.ld + c4 * 4);
+      const float4 t2 = *reinterpret_cast<const float4*>(p.shs + (size_t)n * p.ld + c4 * 4);
+      o.x += b.x * s2.x + t2.x; o.y += b.y * s2.y + t2.y; o.z += b.z * s2.z + t2.z; o.w += b.w * s2.w + t2.w;
+    } else {
+      const float4 b = *reinterpret_cast<const float4*>(p.xres + e);
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    *reinterpret_cast<float4*>(p.out + e) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack: concatenate up to 3 NCHW sources along channels into one zero-padded NHWC tensor
+// (torch.cat at PGNR/models/generator.py:197,232 and the NCHW->NHWC boundary conversion).
+// thread = pixel; grid (ceil(HW/256), B).
+// ---------------------------------------------------------------------------------------------
+struct PackParams {
+  const float* s0; const float* s1; const float* s2;
+  int c0, c1, c2;
+  float* dst; int dC;   // dC multiple of 4
+  int HW;
+};
+
+__global__ __launch_bounds__(256) void k_pack(const PackParams p) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pix >= p.HW) return;
+  float* d = p.dst + ((size_t)n * p.HW + pix) * p.dC;
+  for (int g = 0; g < p.dC / 4; ++g) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = g * 4 + e;
+      float t = 0.f;
+      if (j < p.c0) t = p.s0[((size_t)n * p.c0 + j) * p.HW + pix];
+      else if (j < p.c0 + p.c1) t = p.s1[((size_t)n * p.c1 + (j - p.c0)) * p.HW + pix];
+      else if (j < p.c0 + p.c1 + p.c2) t = p.s2[((size_t)n * p.c2 + (j - p.c0 - p.c1)) * p.HW + pix];
+      v[e] = t;
+    }
+    *reinterpret_cast<float4*>(d + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// NHWC (channel stride sC, first C channels) -> NCHW, for taps / debugging
+__global__ __launch_bounds__(256) void k_unpack(const float* src, int sC, int C, int HW, int ups, int H, int W, float* dst) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pix >= HW) return;
+  (void)ups; (void)H; (void)W;
+  for (int c = 0; c < C; ++c) dst[((size_t)n * C + c) * HW + pix] = src[((size_t)n * HW + pix) * sC + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// driver-side elementwise kernels (NCHW, as the reference driver holds its tensors)
+// ---------------------------------------------------------------------------------------------
+// fuse = img*mask + dain*(1-mask), mask broadcast over C (PGNR/models/evaluator.py:256-258)
+__global__ __launch_bounds__(256) void k_blend(const float* img, const float* mask, const float* dain,
+                                               float* fuse, int C, int HW, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i % HW;
+    const size_t n = i / ((size_t)C * HW);
+    const float m = mask[n * HW + pix];
+    fuse[i] = img[i] * m + dain[i] * (1.f - m);
+  }
+}
+
+// uint8 HWC = uint8(clip(x*0.5+0.5, 0, 1)*255)  (truncation; PGNR/utils/utils.py:129-142; the
+// reference evaluates this in float64, so do we)
+__global__ __launch_bounds__(256) void k_quantise(const float* img, uint8_t* out, int C, int HW, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t c = i % C;
+    const size_t pix = (i / C) % HW;
+    const size_t n = i / ((size_t)C * HW);
+    double v = (double)img[(n * C + c) * HW + pix] * 0.5 + 0.5;
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    out[i] = (uint8_t)(v * 255.0);
+  }
+}
+
+// Bilinear flow warp == grid_sample(img, base + flow*2/(size-1), bilinear, border, align_corners=True)
+// i.e. sample img at (x + fx, y + fy) in pixel units with border clamping.  Extension op.
+__global__ __launch_bounds__(256) void k_warp(const float* img, const float* flow, float* out,
+                                              int C, int H, int W) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int y = pix / W, x = pix % W;
+  // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
+  const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 0) * HW + pix] * (W > 1 ? 2.f / (W - 1) : 0.f);
+  const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 1) * HW + pix] * (H > 1 ? 2.f / (H - 1) : 0.f);
+  float sx = (gx + 1.f) * 0.5f * (W - 1);
+  float sy = (gy + 1.f) * 0.5f * (H - 1);
+  sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
+  sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  const float ax = sx - x0, ay = sy - y0;
+  for (int c = 0; c < C; ++c) {
+    const float* s = img + ((size_t)n * C + c) * HW;
+    const float v = s[y0 * W + x0] * (1.f - ax) * (1.f - ay) + s[y0 * W + x1] * ax * (1.f - ay) +
+                    s[y1 * W + x0] * (1.f - ax) * ay + s[y1 * W + x1] * ax * ay;
+    out[((size_t)n * C + c) * HW + pix] = v;
+  }
+}
+
+}  // namespace rib

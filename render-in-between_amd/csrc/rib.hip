@@ -1,0 +1,1174 @@
+// rib.hip — runtime and C ABI (include/rib.h) of the MI355X-native generator.
+//
+// Host-side responsibilities (all native C++; Python only moves pointers):
+//   * the layer inventory of the generator derived from rib_config
+//     (reference: PGNR/models/generator.py:43-178,315-358,423-491);
+//   * checkpoint ingestion in the reference's state-dict vocabulary, eval-mode spectral-norm
+//     fold (PGNR/models/layers/weight_norm.py:84-85 hook), filter re-layout, one device blob;
+//   * a static launch plan per (B,H,W): workspace layout + the ordered kernel launches that
+//     restate Generator.forward (PGNR/models/generator.py:181-234) and MaskGenerator.forward
+//     (:493-510);
+//   * the autoregressive segment driver (PGNR/models/evaluator.py:238-262).
+#include "kernels.hip.h"
+#include "../../include/rib.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace rib;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+std::string fmt(const char* f, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+
+inline int pad8(int c) { return (c + 7) / 8 * 8; }
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+inline int pick_bk(int cp) { return cp % 32 == 0 ? 32 : (cp % 16 == 0 ? 16 : 8); }
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+// ------------------------------------------------------------------------------------------
+// layer inventory (mirrors render_in_between_amd/spec.py; pinned by the state-dict key test)
+// ------------------------------------------------------------------------------------------
+struct ConvDef {
+  std::string name;
+  int cin = 0, cout = 0, ks = 3, stride = 1;
+  bool spectral = true;
+  int spade_cond = 0;
+  bool in_affine = false;
+  bool used = true;
+  // device blob offsets (floats), filled by finalize
+  size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;
+  int cinp = 0, coutp = 0;
+};
+
+struct TensorDef {
+  std::string name;
+  std::vector<int64_t> dims;
+  bool used;
+  std::vector<float> data;
+  bool set = false;
+};
+
+struct SpadeGroup {   // one SPADE launch: 1 or 2 modulations sharing the normalised tensor
+  std::string key;    // "<block>.0s" / "<block>.0" / "<block>.1"
+  int C = 0, Cp = 0, cond = 0, nsets = 1;
+  size_t w_off = 0, b_off = 0;
+  int npad = 0;       // virtual columns (multiple of 64)
+};
+
+struct Cfg {
+  rib_config c;
+  int nf(int i) const { return std::min(c.max_num_filters, c.num_filters << i); }
+  int mask_nf(int i) const { return std::min(c.mask_max_filters, c.mask_filters << i); }
+  int emb_ch(int i) const { return std::min(c.emb_max_filters, c.emb_filters << i); }
+  int cond_ch(int i) const { return std::min(c.max_num_filters, c.emb_filters << std::min(i, c.emb_down)); }
+  int num_res_blocks() const { return (int)std::ceil((c.num_layers - c.num_down_img) / 2.0) * 2; }
+};
+
+void add_embedder(std::vector<ConvDef>& L, const Cfg& g, const std::string& prefix, int cin, bool used) {
+  ConvDef c; c.name = prefix + ".conv_first"; c.cin = cin; c.cout = g.emb_ch(0); c.used = used; L.push_back(c);
+  for (int i = 0; i < g.c.emb_down; ++i) {
+    ConvDef d; d.name = prefix + ".down_" + std::to_string(i); d.cin = g.emb_ch(i); d.cout = g.emb_ch(i + 1);
+    d.stride = 2; d.used = used; L.push_back(d);
+  }
+}
+void add_spade_block(std::vector<ConvDef>& L, const std::string& name, int cin, int cout, int cond) {
+  const int hidden = std::min(cin, cout);
+  ConvDef a; a.name = name + ".conv_block_0"; a.cin = cin; a.cout = hidden; a.spade_cond = cond; L.push_back(a);
+  ConvDef b; b.name = name + ".conv_block_1"; b.cin = hidden; b.cout = cout; b.spade_cond = cond; L.push_back(b);
+  if (cin != cout) {
+    ConvDef s; s.name = name + ".conv_block_s"; s.cin = cin; s.cout = cout; s.ks = 1; s.spade_cond = cond; L.push_back(s);
+  }
+}
+void add_mask_block(std::vector<ConvDef>& L, const std::string& name, int cin, int cout) {
+  const int hidden = std::min(cin, cout);
+  ConvDef a; a.name = name + ".conv_block_0"; a.cin = cin; a.cout = hidden; a.in_affine = true; L.push_back(a);
+  ConvDef b; b.name = name + ".conv_block_1"; b.cin = hidden; b.cout = cout; b.in_affine = true; L.push_back(b);
+  if (cin != cout) {
+    ConvDef s; s.name = name + ".conv_block_s"; s.cin = cin; s.cout = cout; s.ks = 1; s.in_affine = true; L.push_back(s);
+  }
+}
+
+std::vector<ConvDef> build_inventory(const Cfg& g) {
+  std::vector<ConvDef> L;
+  const rib_config& c = g.c;
+  add_embedder(L, g, "ref_embedding", c.image_nc * 2, true);
+  add_embedder(L, g, "label_embedding", c.label_nc, false);
+  for (int i = c.num_down_img; i >= 0; --i) add_spade_block(L, "up_" + std::to_string(i), g.nf(i + 1), g.nf(i), g.cond_ch(i));
+  { ConvDef d; d.name = "conv_img"; d.cin = c.num_filters; d.cout = c.image_nc; d.spectral = false; L.push_back(d); }
+  { ConvDef d; d.name = "conv_mask"; d.cin = c.num_filters; d.cout = 1; d.spectral = false; d.used = false; L.push_back(d); }
+  { ConvDef d; d.name = "down_first"; d.cin = c.label_nc; d.cout = c.num_filters; d.spectral = false; L.push_back(d); }
+  for (int i = 0; i <= c.num_down_img; ++i) add_spade_block(L, "down_" + std::to_string(i), g.nf(i), g.nf(i + 1), g.cond_ch(i));
+  const int res_ch = g.nf(c.num_down_img + 1);
+  for (int i = 0; i < g.num_res_blocks(); ++i) add_spade_block(L, "res_" + std::to_string(i), res_ch, res_ch, g.cond_ch(c.num_down_img + 1));
+  const std::string m = "flow_network_temp";
+  const char* branches[2] = {"down_lbl", "down_img"};
+  const int bcin[2] = {c.label_nc, c.image_nc * 3};
+  for (int b = 0; b < 2; ++b) {
+    ConvDef d; d.name = m + "." + branches[b] + ".0"; d.cin = bcin[b]; d.cout = c.mask_filters; d.in_affine = true; L.push_back(d);
+    for (int i = 0; i < c.mask_down; ++i) {
+      ConvDef e; e.name = m + "." + branches[b] + "." + std::to_string(i + 1); e.cin = g.mask_nf(i); e.cout = g.mask_nf(i + 1);
+      e.stride = 2; e.in_affine = true; L.push_back(e);
+    }
+  }
+  const int ch = g.mask_nf(c.mask_down);
+  for (int i = 0; i < c.mask_res_blocks; ++i) add_mask_block(L, m + ".res_flow." + std::to_string(i), i == 0 ? ch * 2 : ch, ch);
+  for (int j = 0; j < c.mask_down; ++j) {
+    const int i = c.mask_down - 1 - j;
+    ConvDef d; d.name = m + ".up_flow." + std::to_string(2 * j + 1); d.cin = g.mask_nf(i + 1); d.cout = g.mask_nf(i); d.in_affine = true; L.push_back(d);
+  }
+  { ConvDef d; d.name = m + ".conv_mask.0"; d.cin = c.mask_filters; d.cout = 1; d.spectral = false; L.push_back(d); }
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel variant table
+// ------------------------------------------------------------------------------------------
+typedef void (*IgemmFn)(const IgemmParams);
+struct Variant {
+  int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
+  IgemmFn fn;
+  int TH() const { return (32 / FRW) * MF * WM; }
+  int TW() const { return FRW; }
+  int BN() const { return 32 * NF * WN; }
+};
+#define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP>}
+
+const Variant kVariants[] = {
+    // 3x3 stride 1
+    RIB_V(16, 4, 1, 1, 1, 8, 1, 3, false, false),  RIB_V(16, 4, 1, 1, 2, 8, 1, 3, false, false),
+    RIB_V(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 3, false, false),
+    RIB_V(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 3, false, false),
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false),
+    // 3x3 stride 2
+    RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
+    // 3x3 on a nearest-x2-upsampled input
+    RIB_V(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 32, 1, 3, true, false),
+    // 1x1
+    RIB_V(16, 4, 1, 1, 1, 16, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 1, false, false),
+    RIB_V(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, false),
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 1, false, false),
+    // SPADE: 1x1 gamma/beta GEMM on the condition map + modulate epilogue
+    RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_V(8, 1, 4, 1, 2, 32, 1, 1, false, true),
+};
+const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+// choose a variant: exact (BK,STRIDE,KS,UPS,SPADE); geometry by column count and grid fill
+const Variant* pick_variant(int BK, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout) {
+  const Variant* best = nullptr;
+  double best_score = -1e30;
+  for (int i = 0; i < kNumVariants; ++i) {
+    const Variant& v = kVariants[i];
+    if (v.BK != BK || v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade) continue;
+    const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
+    const long ntiles = (ncols + v.BN() - 1) / v.BN();
+    const long wgs = tiles * ntiles * B;
+    // useful fraction of the MFMA work the grid issues (tile overhang in pixels and columns)
+    const double eff_n = (double)ncols / (double)(ntiles * v.BN());
+    const double eff_m = (double)Hout * Wout / (double)(tiles * v.TH() * v.TW());
+    const double fill = std::min(1.0, (double)wgs / 512.0);   // 2 workgroups per CU fills the chip
+    // bigger tiles reuse operands better: mild preference
+    const double reuse = 1.0 + 0.05 * std::log2((double)v.TH() * v.TW() * v.BN() / 1024.0);
+    const double score = eff_n * eff_m * fill * reuse;
+    if (score > best_score) { best_score = score; best = &v; }
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch plan
+// ------------------------------------------------------------------------------------------
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD };
+
+// pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
+// (floats); resolved at launch time.
+enum PtrSpace { PS_NULL = 0, PS_WS, PS_WEIGHT, PS_USER };
+enum UserSlot { U_LABEL = 0, U_FAKE, U_PREV, U_IMG, U_MASK, U_COUNT };
+struct PRef {
+  PtrSpace sp = PS_NULL;
+  size_t off = 0;   // bytes for WS, floats for WEIGHT, slot id for USER
+};
+
+struct Op {
+  OpKind kind;
+  int kclass;
+  std::string name;
+  // igemm
+  const Variant* var = nullptr;
+  IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
+  PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1;
+  dim3 grid;
+  double flops = 0;
+  // finalize
+  FinalizeParams fp; PRef f_part, f_gamma, f_beta, f_scale, f_shift;
+  // pool
+  PoolParams pp; PRef p_x, p_y, p_stat;
+  // in_add
+  InAddParams ap; PRef a_t1, a_sc1, a_sh1, a_ts, a_scs, a_shs, a_x, a_out;
+  // pack
+  PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
+};
+
+struct Tap { std::string name; size_t off; int Cp, C, H, W; };
+
+struct Act {       // NHWC activation in the workspace
+  size_t off = 0;  // bytes
+  int Cp = 0, C = 0, H = 0, W = 0;
+};
+struct Norm {      // (scale, shift) arrays [B][ld]
+  size_t sc = 0, sh = 0; int ld = 0;
+  bool valid = false;
+};
+
+struct Plan {
+  int B, H, W;
+  size_t ws_bytes = 0;
+  std::vector<Op> ops;
+  std::vector<Tap> taps;
+  double flops[RIB_KC_COUNT] = {0};
+};
+
+}  // namespace
+
+struct rib_handle {
+  Cfg g;
+  int device = 0;
+  std::string err;
+  std::vector<ConvDef> convs;
+  std::map<std::string, int> conv_index;
+  std::vector<TensorDef> tensors;
+  std::map<std::string, int> tensor_index;
+  std::vector<SpadeGroup> spades;
+  std::map<std::string, int> spade_index;
+  float* d_blob = nullptr;
+  std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
+  size_t blob_floats = 0;
+  bool weights_ready = false;
+  std::map<uint64_t, std::unique_ptr<Plan>> plans;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  int64_t prof_launches[RIB_KC_COUNT] = {0};
+  double prof_ms[RIB_KC_COUNT] = {0};
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->err = fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RIB_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+int fail(rib_handle* h, int code, const std::string& msg) {
+  h->err = msg;
+  return code;
+}
+
+const ConvDef& conv_of(const rib_handle* h, const std::string& name) {
+  return h->convs[h->conv_index.at(name)];
+}
+
+// ------------------------------------------------------------------------------------------
+// weight layout: sizes are fixed by the config, so offsets are assigned at create time
+// ------------------------------------------------------------------------------------------
+void assign_weight_layout(rib_handle* h) {
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { size_t o = off; off += (nfloats + 63) / 64 * 64; return o; };
+  for (auto& c : h->convs) {
+    if (!c.used) continue;
+    c.cinp = pad8(c.cin);
+    c.coutp = pad32(c.cout);
+    c.w_off = take((size_t)c.coutp * c.ks * c.ks * c.cinp);
+    c.b_off = take(c.coutp);
+    if (c.in_affine) { c.g_off = take(c.coutp); c.be_off = take(c.coutp); }
+  }
+  // SPADE groups: block_0 (+ block_s when the shortcut is learned) share one launch
+  for (auto& c : h->convs) {
+    if (!c.used || !c.spade_cond) continue;
+    const std::string blk = c.name.substr(0, c.name.rfind(".conv_block_"));
+    const std::string which = c.name.substr(c.name.size() - 1);
+    if (which == "s") continue;   // folded into the "0" group
+    SpadeGroup sg;
+    sg.C = c.cin; sg.Cp = pad8(c.cin); sg.cond = c.spade_cond;
+    sg.nsets = (which == "0" && h->conv_index.count(blk + ".conv_block_s")) ? 2 : 1;
+    sg.key = blk + "." + which;
+    sg.npad = (sg.nsets * sg.Cp + 31) / 32 * 64;
+    sg.w_off = take((size_t)sg.npad * pad8(sg.cond));
+    sg.b_off = take(sg.npad);
+    h->spade_index[sg.key] = (int)h->spades.size();
+    h->spades.push_back(sg);
+  }
+  h->blob_floats = off;
+}
+
+void register_tensors(rib_handle* h) {
+  auto add = [&](const std::string& n, std::vector<int64_t> d, bool used) {
+    TensorDef t; t.name = n; t.dims = d; t.used = used;
+    h->tensor_index[n] = (int)h->tensors.size();
+    h->tensors.push_back(t);
+  };
+  for (auto& c : h->convs) {
+    if (c.spade_cond) {
+      add(c.name + ".layers.norm.mlps.0.0.layers.conv.weight", {2 * c.cin, c.spade_cond, 1, 1}, c.used);
+      add(c.name + ".layers.norm.mlps.0.0.layers.conv.bias", {2 * c.cin}, c.used);
+    }
+    const std::string p = c.name + ".layers.conv";
+    if (c.spectral) {
+      add(p + ".bias", {c.cout}, c.used);
+      add(p + ".weight_orig", {c.cout, c.cin, c.ks, c.ks}, c.used);
+      add(p + ".weight_u", {c.cout}, c.used);
+      add(p + ".weight_v", {(int64_t)c.cin * c.ks * c.ks}, c.used);
+    } else {
+      add(p + ".weight", {c.cout, c.cin, c.ks, c.ks}, c.used);
+      add(p + ".bias", {c.cout}, c.used);
+    }
+    if (c.in_affine) {
+      add(c.name + ".layers.norm.weight", {c.cout}, c.used);
+      add(c.name + ".layers.norm.bias", {c.cout}, c.used);
+    }
+  }
+}
+
+const std::vector<float>* tensor_data(rib_handle* h, const std::string& name) {
+  auto it = h->tensor_index.find(name);
+  if (it == h->tensor_index.end()) return nullptr;
+  TensorDef& t = h->tensors[it->second];
+  return t.set ? &t.data : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// plan builder
+// ------------------------------------------------------------------------------------------
+struct Builder {
+  rib_handle* h;
+  Plan* P;
+  int B;
+  size_t ws = 0;
+  std::string error;
+
+  size_t alloc(size_t bytes) { size_t o = ws; ws += align256(bytes); return o; }
+  Act act(int C, int H, int W) {
+    Act a; a.C = C; a.Cp = pad8(C); a.H = H; a.W = W;
+    a.off = alloc((size_t)B * H * W * a.Cp * sizeof(float));
+    return a;
+  }
+  Norm norm(int Cp) {
+    Norm n; n.ld = Cp; n.valid = true;
+    n.sc = alloc((size_t)B * Cp * sizeof(float));
+    n.sh = alloc((size_t)B * Cp * sizeof(float));
+    return n;
+  }
+  static PRef WS(size_t off) { PRef r; r.sp = PS_WS; r.off = off; return r; }
+  static PRef WT(size_t off) { PRef r; r.sp = PS_WEIGHT; r.off = off; return r; }
+  static PRef US(int slot) { PRef r; r.sp = PS_USER; r.off = (size_t)slot; return r; }
+  void tap(const std::string& name, const Act& a) { P->taps.push_back(Tap{name, a.off, a.Cp, a.C, a.H, a.W}); }
+
+  // ---- generic convolution launch --------------------------------------------------------
+  struct ConvArgs {
+    const ConvDef* cd = nullptr;
+    Act in;                 // input activation (stored size; half-res when ups)
+    bool ups = false;
+    const Norm* pro = nullptr; size_t pro_choff = 0;   // prologue affine (+channel offset into the arrays)
+    bool pro_lrelu = false;
+    Act out; int yoff = 0;  // destination buffer and channel offset
+    int cout_store = -1;    // columns stored (default: out slice padded width)
+    int act = ACT_NONE;
+    const Act* res = nullptr;
+    PRef y_nchw;            // optional NCHW copy
+    PRef y_user;            // when set, y is this user tensor (yC = cout exactly)
+    bool want_stats = false;
+    Norm* stats_out = nullptr; size_t stats_choff = 0;  // finalize target (+channel offset)
+    bool affine = false;    // finalize with the conv's IN gamma/beta
+  };
+
+  bool conv(const ConvArgs& a, const std::string& opname) {
+    const ConvDef& c = *a.cd;
+    const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
+    const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
+    if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
+    const int BK = pick_bk(c.cinp);
+    const Variant* v = pick_variant(BK, c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout);
+    if (!v) { error = fmt("%s: no kernel variant for BK=%d stride=%d ks=%d ups=%d", opname.c_str(), BK, c.stride, c.ks, (int)a.ups); return false; }
+    Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = opname; op.var = v;
+    IgemmParams& p = op.ip;
+    memset(&p, 0, sizeof p);
+    p.Hin = a.in.H; p.Win = a.in.W; p.xC = a.in.Cp; p.Cin = c.cinp;
+    p.pro_ld = a.pro ? a.pro->ld : 0; p.pro_lrelu = a.pro_lrelu ? 1 : 0;
+    p.CoutPad = c.coutp;
+    p.Hout = Hout; p.Wout = Wout;
+    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
+    p.act = a.act;
+    op.x = WS(a.in.off);
+    if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
+    op.w = WT(c.w_off); op.bias = WT(c.b_off);
+    if (a.y_user.sp != PS_NULL) {
+      op.y = a.y_user; p.yC = c.cout; p.yoff = 0; p.Cout = c.cout;
+    } else {
+      op.y = WS(a.out.off); p.yC = a.out.Cp; p.yoff = a.yoff;
+      p.Cout = a.cout_store >= 0 ? a.cout_store : pad8(c.cout);
+      if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
+    }
+    if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; }
+    op.y_nchw = a.y_nchw;
+    const int tiles = p.tilesX * p.tilesY;
+    size_t part_off = 0;
+    if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
+    op.grid = dim3(tiles, (c.coutp + v->BN() - 1) / v->BN(), B);
+    op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B;
+    P->flops[RIB_KC_IGEMM] += op.flops;
+    P->ops.push_back(op);
+    if (a.want_stats) {
+      Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
+      memset(&f.fp, 0, sizeof f.fp);
+      f.fp.tiles = tiles; f.fp.Cs = c.coutp; f.fp.C = pad8(c.cout);
+      f.fp.ld = a.stats_out->ld; f.fp.off = (int)a.stats_choff;
+      f.fp.inv_count = 1.0f / ((float)Hout * (float)Wout); f.fp.eps = 1e-5f;
+      f.f_part = WS(part_off);
+      if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
+      f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
+      f.grid = dim3(c.coutp / 32, B, 1);
+      P->ops.push_back(f);
+    }
+    return true;
+  }
+
+  // ---- SPADE launch: ys0 (= lrelu(mod0(x))), optional ys1 (= mods(x), no activation) -------
+  bool spade(const std::string& key, const Act& cond, const Act& x, bool x_ups, const Norm& nx,
+             Act* ys0, Act* ys1, bool act0) {
+    const SpadeGroup& sg = h->spades[h->spade_index.at(key)];
+    const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
+    if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
+    if (cond.Cp != pad8(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
+    if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
+    const Variant* v = pick_variant(32, 1, 1, false, true, sg.npad, B, Hout, Wout);
+    if (!v) { error = "no SPADE variant"; return false; }
+    *ys0 = act(sg.C, Hout, Wout);
+    if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
+    Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = v;
+    IgemmParams& p = op.ip;
+    memset(&p, 0, sizeof p);
+    p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
+    p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout;
+    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
+    p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
+    p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
+    op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off);
+    op.xm = WS(x.off); op.m_scale = WS(nx.sc); op.m_shift = WS(nx.sh);
+    op.ys0 = WS(ys0->off); if (sg.nsets == 2) op.ys1 = WS(ys1->off);
+    op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + v->BN() - 1) / v->BN(), B);
+    op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
+    P->flops[RIB_KC_SPADE] += op.flops;
+    P->ops.push_back(op);
+    return true;
+  }
+
+  // ---- Res2dBlock 'NACNAC' (PGNR/models/layers/residual.py:129-151) -------------------------
+  bool spade_block(const std::string& name, const Act& x, bool x_ups, const Norm& nx, const Act& cond,
+                   Act* out, Norm* nout) {
+    const ConvDef& c0 = conv_of(h, name + ".conv_block_0");
+    const ConvDef& c1 = conv_of(h, name + ".conv_block_1");
+    const bool learned = h->conv_index.count(name + ".conv_block_s") > 0;
+    const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
+    Act ys0, ys1;
+    if (!spade(name + ".0", cond, x, x_ups, nx, &ys0, &ys1, true)) return false;
+    Act hbuf = act(c0.cout, Hout, Wout);
+    Norm nh = norm(hbuf.Cp);
+    { ConvArgs a; a.cd = &c0; a.in = ys0; a.out = hbuf; a.want_stats = true; a.stats_out = &nh;
+      if (!conv(a, name + ".conv_block_0")) return false; }
+    tap(name + ".h", hbuf);
+    Act y1, dummy;
+    if (!spade(name + ".1", cond, hbuf, false, nh, &y1, &dummy, true)) return false;
+    Act outs;
+    if (learned) {
+      const ConvDef& cs = conv_of(h, name + ".conv_block_s");
+      outs = act(cs.cout, Hout, Wout);
+      ConvArgs a; a.cd = &cs; a.in = ys1; a.out = outs;
+      if (!conv(a, name + ".conv_block_s")) return false;
+    } else if (x_ups) { error = name + ": identity shortcut on an upsampled input"; return false; }
+    *out = act(c1.cout, Hout, Wout);
+    { ConvArgs a; a.cd = &c1; a.in = y1; a.out = *out; a.res = learned ? &outs : &x;
+      if (nout) { *nout = norm(out->Cp); a.want_stats = true; a.stats_out = nout; }
+      if (!conv(a, name + ".conv_block_1")) return false; }
+    tap(name, *out);
+    return true;
+  }
+
+  bool build() {
+    const Cfg& g = h->g;
+    const rib_config& c = g.c;
+    const int H = P->H, W = P->W;
+    const int D = c.num_down_img;
+
+    // ---- boundary: NCHW user tensors -> NHWC (+concat, +zero channel padding) ----
+    Act L = act(c.label_nc, H, W);
+    Act Ein = act(c.image_nc * 2, H, W);
+    Act I9 = act(c.image_nc * 3, H, W);
+    auto pack = [&](const std::string& nm, const Act& dst, int s0, int c0, int s1, int c1) {
+      Op op; op.kind = OP_PACK; op.kclass = RIB_KC_PACK; op.name = nm;
+      memset(&op.kp, 0, sizeof op.kp);
+      op.kp.c0 = c0; op.kp.c1 = c1; op.kp.c2 = 0; op.kp.dC = dst.Cp; op.kp.HW = H * W;
+      op.k_s0 = US(s0); if (c1) op.k_s1 = US(s1);
+      op.k_dst = WS(dst.off);
+      op.grid = dim3((H * W + 255) / 256, B, 1);
+      P->ops.push_back(op);
+    };
+    pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
+    pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
+    pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
+
+    // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
+    std::vector<Act> cond(c.emb_down + 1);
+    {
+      const ConvDef& cf = conv_of(h, "ref_embedding.conv_first");
+      cond[0] = act(cf.cout, H, W);
+      ConvArgs a; a.cd = &cf; a.in = Ein; a.out = cond[0]; a.act = ACT_LRELU;
+      if (!conv(a, "ref_embedding.conv_first")) return false;
+      tap("cond_0", cond[0]);
+      for (int i = 0; i < c.emb_down; ++i) {
+        const ConvDef& cd = conv_of(h, "ref_embedding.down_" + std::to_string(i));
+        cond[i + 1] = act(cd.cout, cond[i].H / 2, cond[i].W / 2);
+        ConvArgs b; b.cd = &cd; b.in = cond[i]; b.out = cond[i + 1]; b.act = ACT_LRELU;
+        if (!conv(b, cd.name)) return false;
+        tap("cond_" + std::to_string(i + 1), cond[i + 1]);
+      }
+    }
+
+    // ---- main generator (generator.py:201-228) ----
+    Act x; Norm nx;
+    {
+      const ConvDef& df = conv_of(h, "down_first");
+      x = act(df.cout, H, W); nx = norm(x.Cp);
+      ConvArgs a; a.cd = &df; a.in = L; a.out = x; a.want_stats = true; a.stats_out = &nx;
+      if (!conv(a, "down_first")) return false;
+      tap("down_first", x);
+    }
+    for (int i = 0; i <= D; ++i) {
+      Act out; Norm nout;
+      const bool last = (i == D);
+      if (!spade_block("down_" + std::to_string(i), x, false, nx, cond[std::min(c.emb_down, i)], &out, last ? &nout : nullptr)) return false;
+      if (!last) {   // self.downsample = AvgPool2d(3, 2, 1) (generator.py:127,207-208)
+        if (out.Cp % 4 != 0 || 256 % (out.Cp / 4) != 0) { error = "avgpool: unsupported channel count"; return false; }
+        Act pooled = act(out.C, out.H / 2, out.W / 2);
+        Norm np = norm(pooled.Cp);
+        const int slots = 256 / (out.Cp / 4), ppb = slots * 4;
+        const int blocks = (pooled.H * pooled.W + ppb - 1) / ppb;
+        const size_t part = alloc((size_t)B * blocks * 2 * out.Cp * sizeof(float));
+        Op op; op.kind = OP_POOL; op.kclass = RIB_KC_POOL; op.name = "down_" + std::to_string(i) + ".pool";
+        memset(&op.pp, 0, sizeof op.pp);
+        op.pp.H = out.H; op.pp.W = out.W; op.pp.C = out.Cp; op.pp.blocks = blocks;
+        op.p_x = WS(out.off); op.p_y = WS(pooled.off); op.p_stat = WS(part);
+        op.grid = dim3(blocks, B, 1);
+        P->ops.push_back(op);
+        Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = op.name + ".stats";
+        memset(&f.fp, 0, sizeof f.fp);
+        f.fp.tiles = blocks; f.fp.Cs = out.Cp; f.fp.C = out.Cp; f.fp.ld = np.ld; f.fp.off = 0;
+        f.fp.inv_count = 1.0f / ((float)pooled.H * (float)pooled.W); f.fp.eps = 1e-5f;
+        f.f_part = WS(part); f.f_scale = WS(np.sc); f.f_shift = WS(np.sh);
+        f.grid = dim3((out.Cp + 31) / 32, B, 1);
+        P->ops.push_back(f);
+        x = pooled; nx = np;
+      } else { x = out; nx = nout; }
+    }
+    const int jres = std::min(c.emb_down, D + 1);
+    for (int i = 0; i < g.num_res_blocks(); ++i) {
+      Act out; Norm nout;
+      if (!spade_block("res_" + std::to_string(i), x, false, nx, cond[jres], &out, &nout)) return false;
+      x = out; nx = nout;
+    }
+    bool ups = false;
+    for (int i = D; i >= 0; --i) {
+      Act out; Norm nout;
+      // statistics of a nearest-x2 upsampled tensor equal those of the tensor itself, so the
+      // producer's (scale, shift) are reused and the upsample is folded into the consumer's read
+      if (!spade_block("up_" + std::to_string(i), x, ups, nx, cond[std::min(i, c.emb_down)], &out, i != 0 ? &nout : nullptr)) return false;
+      x = out; nx = nout; ups = true;
+    }
+    {   // conv_img 'AC' + tanh (generator.py:114-116,228); also lands in img9[6:9]
+      const ConvDef& ci = conv_of(h, "conv_img");
+      ConvArgs a; a.cd = &ci; a.in = x; a.pro_lrelu = true; a.out = I9; a.yoff = c.image_nc * 2;
+      a.cout_store = c.image_nc; a.act = ACT_TANH; a.y_nchw = US(U_IMG);
+      if (!conv(a, "conv_img")) return false;
+    }
+
+    // ---- MaskGenerator (generator.py:493-510) ----
+    const std::string m = "flow_network_temp";
+    const int chm = g.mask_nf(c.mask_down);
+    const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
+    if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
+    Act CAT = act(2 * chm, Hm, Wm);
+    Norm ncat = norm(CAT.Cp);
+    const char* branches[2] = {"down_lbl", "down_img"};
+    const Act* bin[2] = {&L, &I9};
+    for (int b = 0; b < 2; ++b) {
+      Act cur = *bin[b]; Norm ncur; bool have = false;
+      for (int i = 0; i <= c.mask_down; ++i) {
+        const ConvDef& cd = conv_of(h, m + "." + branches[b] + "." + std::to_string(i));
+        const bool lastl = (i == c.mask_down);
+        Act o = lastl ? CAT : act(cd.cout, i == 0 ? cur.H : cur.H / 2, i == 0 ? cur.W : cur.W / 2);
+        Norm no = lastl ? ncat : norm(pad8(cd.cout));
+        ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
+        if (have) { a.pro = &ncur; a.pro_lrelu = true; }
+        if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; }
+        a.want_stats = true; a.stats_out = &no; a.affine = true;
+        if (!conv(a, cd.name)) return false;
+        if (!lastl) tap(std::string("mask.") + (b == 0 ? "lbl_" : "img_") + std::to_string(i) + ".raw", o);
+        cur = o; ncur = no; have = true;
+      }
+    }
+    tap("mask.cat.raw", CAT);
+    Act r; bool first = true;
+    for (int i = 0; i < c.mask_res_blocks; ++i) {
+      const std::string bn = m + ".res_flow." + std::to_string(i);
+      const ConvDef& c0 = conv_of(h, bn + ".conv_block_0");
+      const ConvDef& c1 = conv_of(h, bn + ".conv_block_1");
+      const bool learned = h->conv_index.count(bn + ".conv_block_s") > 0;
+      const Act& xin = first ? CAT : r;
+      Act t0 = act(c0.cout, Hm, Wm); Norm n0 = norm(t0.Cp);
+      { ConvArgs a; a.cd = &c0; a.in = xin; a.out = t0; if (first) { a.pro = &ncat; a.pro_lrelu = true; }
+        a.want_stats = true; a.stats_out = &n0; a.affine = true;
+        if (!conv(a, c0.name)) return false; }
+      Act t1 = act(c1.cout, Hm, Wm); Norm n1 = norm(t1.Cp);
+      { ConvArgs a; a.cd = &c1; a.in = t0; a.out = t1; a.pro = &n0; a.pro_lrelu = true;
+        a.want_stats = true; a.stats_out = &n1; a.affine = true;
+        if (!conv(a, c1.name)) return false; }
+      Act ts; Norm ns;
+      if (learned) {
+        const ConvDef& cs = conv_of(h, bn + ".conv_block_s");
+        ts = act(cs.cout, Hm, Wm); ns = norm(ts.Cp);
+        ConvArgs a; a.cd = &cs; a.in = xin; a.out = ts; if (first) { a.pro = &ncat; a.pro_lrelu = true; }
+        a.want_stats = true; a.stats_out = &ns; a.affine = true;
+        if (!conv(a, cs.name)) return false;
+      } else if (first) { error = "mask res block 0 must have a learned shortcut"; return false; }
+      Act o = act(c1.cout, Hm, Wm);
+      Op op; op.kind = OP_INADD; op.kclass = RIB_KC_ELTWISE; op.name = bn + ".join";
+      memset(&op.ap, 0, sizeof op.ap);
+      op.ap.C = o.Cp; op.ap.HW = Hm * Wm; op.ap.ld = n1.ld;
+      op.a_t1 = WS(t1.off); op.a_sc1 = WS(n1.sc); op.a_sh1 = WS(n1.sh);
+      if (learned) { op.a_ts = WS(ts.off); op.a_scs = WS(ns.sc); op.a_shs = WS(ns.sh); }
+      else op.a_x = WS(xin.off);
+      op.a_out = WS(o.off);
+      const size_t total = (size_t)Hm * Wm * (o.Cp / 4);
+      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), B, 1);
+      P->ops.push_back(op);
+      tap("mask.res_" + std::to_string(i), o);
+      r = o; first = false;
+    }
+    Act cur = r; Norm ncur; bool have = false;
+    for (int j = 0; j < c.mask_down; ++j) {
+      const ConvDef& cd = conv_of(h, m + ".up_flow." + std::to_string(2 * j + 1));
+      Act o = act(cd.cout, cur.H * 2, cur.W * 2); Norm no = norm(o.Cp);
+      ConvArgs a; a.cd = &cd; a.in = cur; a.ups = true; a.out = o;
+      if (have) { a.pro = &ncur; a.pro_lrelu = true; }
+      a.want_stats = true; a.stats_out = &no; a.affine = true;
+      if (!conv(a, cd.name)) return false;
+      tap("mask.up_" + std::to_string(j) + ".raw", o);
+      cur = o; ncur = no; have = true;
+    }
+    {
+      const ConvDef& cm = conv_of(h, m + ".conv_mask.0");
+      ConvArgs a; a.cd = &cm; a.in = cur; if (have) { a.pro = &ncur; a.pro_lrelu = true; }
+      a.act = ACT_SIGMOID; a.y_user = US(U_MASK);
+      if (!conv(a, cm.name)) return false;
+    }
+    // chain scratch: fused frame of the previous step (NCHW)
+    P->ws_bytes = ws;
+    return true;
+  }
+};
+
+Plan* get_plan(rib_handle* h, int B, int H, int W) {
+  const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W;
+  auto it = h->plans.find(key);
+  if (it != h->plans.end()) return it->second.get();
+  const int mult = 1 << std::max(h->g.c.num_down_img, h->g.c.mask_down);
+  if (B < 1 || H < mult || W < mult || H % mult || W % mult) {
+    h->err = fmt("unsupported shape B=%d H=%d W=%d: H and W must be positive multiples of %d (SURVEY F5)", B, H, W, mult);
+    return nullptr;
+  }
+  std::unique_ptr<Plan> P(new Plan());
+  P->B = B; P->H = H; P->W = W;
+  Builder b; b.h = h; b.P = P.get(); b.B = B;
+  if (!b.build()) { h->err = "plan: " + b.error; return nullptr; }
+  Plan* raw = P.get();
+  h->plans[key] = std::move(P);
+  return raw;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------
+struct Resolver {
+  char* ws; float* blob; const void* user[U_COUNT];
+  template <typename T> T* get(const PRef& r) const {
+    switch (r.sp) {
+      case PS_WS: return reinterpret_cast<T*>(ws + r.off);
+      case PS_WEIGHT: return reinterpret_cast<T*>(blob + r.off);
+      case PS_USER: return reinterpret_cast<T*>(const_cast<void*>(user[r.off]));
+      default: return nullptr;
+    }
+  }
+};
+
+int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
+  for (Op& op : P->ops) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+      HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+      HIP_TRY(h, hipEventRecord(e0, st));
+    }
+    switch (op.kind) {
+      case OP_IGEMM: {
+        IgemmParams p = op.ip;
+        p.x = R.get<const float>(op.x); p.pro_scale = R.get<const float>(op.pro_scale); p.pro_shift = R.get<const float>(op.pro_shift);
+        p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
+        p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
+        p.stat_part = R.get<float>(op.stat);
+        p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
+        p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
+        hipLaunchKernelGGL(op.var->fn, op.grid, dim3(256), 0, st, p);
+      } break;
+      case OP_FINALIZE: {
+        FinalizeParams p = op.fp;
+        p.part = R.get<const float>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
+        p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
+        hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(256), 0, st, p);
+      } break;
+      case OP_POOL: {
+        PoolParams p = op.pp;
+        p.x = R.get<const float>(op.p_x); p.y = R.get<float>(op.p_y); p.stat_part = R.get<float>(op.p_stat);
+        hipLaunchKernelGGL(k_avgpool, op.grid, dim3(256), 0, st, p);
+      } break;
+      case OP_INADD: {
+        InAddParams p = op.ap;
+        p.t1 = R.get<const float>(op.a_t1); p.sc1 = R.get<const float>(op.a_sc1); p.sh1 = R.get<const float>(op.a_sh1);
+        p.ts = R.get<const float>(op.a_ts); p.scs = R.get<const float>(op.a_scs); p.shs = R.get<const float>(op.a_shs);
+        p.xres = R.get<const float>(op.a_x); p.out = R.get<float>(op.a_out);
+        hipLaunchKernelGGL(k_in_add, op.grid, dim3(256), 0, st, p);
+      } break;
+      case OP_PACK: {
+        PackParams p = op.kp;
+        p.s0 = R.get<const float>(op.k_s0); p.s1 = R.get<const float>(op.k_s1); p.s2 = R.get<const float>(op.k_s2);
+        p.dst = R.get<float>(op.k_dst);
+        hipLaunchKernelGGL(k_pack, op.grid, dim3(256), 0, st, p);
+      } break;
+    }
+    if (h->profiling) {
+      HIP_TRY(h, hipEventRecord(e1, st));
+      h->prof_events.push_back({op.kclass, {e0, e1}});
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+int check_ready(rib_handle* h) {
+  if (!h) return RIB_ERR_INVALID;
+  if (!h->weights_ready) return fail(h, RIB_ERR_STATE, "weights not loaded: call rib_finalize_weights() or rib_import_weights() first");
+  return RIB_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int rib_create(const rib_config* cfg, int device, rib_handle** out) {
+  if (!cfg || !out) { g_create_error = "rib_create: null argument"; return RIB_ERR_INVALID; }
+  *out = nullptr;
+  const rib_config& c = *cfg;
+  auto bad = [&](const std::string& m) { g_create_error = "rib_create: " + m; return RIB_ERR_UNSUPPORTED; };
+  if (c.label_nc < 1 || c.image_nc < 1 || c.num_filters < 1 || c.num_down_img < 1 || c.mask_down < 1 ||
+      c.emb_filters < 1 || c.mask_filters < 1 || c.mask_res_blocks < 1 || c.num_layers < c.num_down_img)
+    return bad("invalid hyper-parameters");
+  if (c.emb_down != c.num_down_img) return bad("embed.num_downsamples must equal num_downsamples_img (HSM.yaml: 4/4)");
+  std::unique_ptr<rib_handle> h(new rib_handle());
+  h->g.c = c; h->device = device;
+  for (int i = 0; i <= c.emb_down; ++i) {
+    if (h->g.cond_ch(i) != h->g.emb_ch(i)) return bad("embed/generator max_num_filters disagree on the cond map width");
+    if (h->g.emb_ch(i) % 32 != 0) return bad(fmt("embed width %d at level %d is not a multiple of 32", h->g.emb_ch(i), i));
+  }
+  for (int i = 1; i <= c.mask_down; ++i)
+    if (h->g.mask_nf(i - 1) % 32 != 0) return bad("mask.num_filters must be a multiple of 32 (stride-2 kernels use 32-channel chunks)");
+  for (int i = 0; i <= c.num_down_img + 1; ++i) {
+    const int ch = h->g.nf(i);
+    if (ch % 4 != 0 || 256 % (ch / 4 > 0 ? ch / 4 : 1) != 0 || ch > 1024) return bad(fmt("generator width %d unsupported (power-of-two multiples of 4 up to 1024)", ch));
+  }
+  h->convs = build_inventory(h->g);
+  for (size_t i = 0; i < h->convs.size(); ++i) h->conv_index[h->convs[i].name] = (int)i;
+  register_tensors(h.get());
+  assign_weight_layout(h.get());
+  if (device >= 0) {   // device < 0: host-only handle (inventory, plans, weight fold; no launches)
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float));
+    if (e != hipSuccess) { g_create_error = fmt("rib_create: device %d: %s", device, hipGetErrorString(e)); return RIB_ERR_HIP; }
+  }
+  *out = h.release();
+  return RIB_OK;
+}
+
+void rib_destroy(rib_handle* h) {
+  if (!h) return;
+  if (h->d_blob) (void)hipFree(h->d_blob);
+  for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+  delete h;
+}
+
+const char* rib_last_error(const rib_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rib_num_tensors(const rib_handle* h) { return h ? (int)h->tensors.size() : RIB_ERR_INVALID; }
+
+int rib_tensor_info(const rib_handle* h, int idx, const char** name, int* ndim, int64_t dims[4], int* used) {
+  if (!h || idx < 0 || idx >= (int)h->tensors.size()) return RIB_ERR_INVALID;
+  const TensorDef& t = h->tensors[idx];
+  if (name) *name = t.name.c_str();
+  if (ndim) *ndim = (int)t.dims.size();
+  if (dims) for (size_t i = 0; i < 4; ++i) dims[i] = i < t.dims.size() ? t.dims[i] : 1;
+  if (used) *used = t.used ? 1 : 0;
+  return RIB_OK;
+}
+
+int rib_set_tensor(rib_handle* h, const char* name, const float* data, int ndim, const int64_t* dims) {
+  if (!h || !name || !data || !dims) return RIB_ERR_INVALID;
+  auto it = h->tensor_index.find(name);
+  if (it == h->tensor_index.end()) return fail(h, RIB_ERR_INVALID, fmt("unexpected key '%s' in state_dict (strict load, PGNR/utils/utils.py:119)", name));
+  TensorDef& t = h->tensors[it->second];
+  if (ndim != (int)t.dims.size()) return fail(h, RIB_ERR_INVALID, fmt("'%s': rank %d, expected %zu", name, ndim, t.dims.size()));
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (dims[i] != t.dims[i]) return fail(h, RIB_ERR_INVALID, fmt("size mismatch for '%s' (dim %d: %lld vs %lld)", name, i, (long long)dims[i], (long long)t.dims[i]));
+    n *= (size_t)dims[i];
+  }
+  if (t.used) t.data.assign(data, data + n);   // tensors of never-called modules are accepted and dropped
+  t.set = true;
+  h->weights_ready = false;
+  return RIB_OK;
+}
+
+int rib_finalize_weights(rib_handle* h) {
+  if (!h) return RIB_ERR_INVALID;
+  for (auto& t : h->tensors)
+    if (!t.set) return fail(h, RIB_ERR_MISSING, fmt("missing key '%s' in state_dict (strict load)", t.name.c_str()));
+  std::vector<float> blob(h->blob_floats, 0.f);
+  for (auto& c : h->convs) {
+    if (!c.used) continue;
+    const std::string p = c.name + ".layers.conv";
+    const int K = c.cin * c.ks * c.ks;
+    const std::vector<float>* w = nullptr;
+    double sigma = 1.0;
+    if (c.spectral) {
+      w = tensor_data(h, p + ".weight_orig");
+      const std::vector<float>& u = *tensor_data(h, p + ".weight_u");
+      const std::vector<float>& v = *tensor_data(h, p + ".weight_v");
+      // sigma = u . (W_mat v): eval-mode spectral norm, u and v exactly as stored
+      double s = 0.0;
+      for (int o = 0; o < c.cout; ++o) {
+        double row = 0.0;
+        for (int k = 0; k < K; ++k) row += (double)(*w)[(size_t)o * K + k] * (double)v[k];
+        s += (double)u[o] * row;
+      }
+      sigma = s;
+      if (sigma == 0.0 || !std::isfinite(sigma)) return fail(h, RIB_ERR_INVALID, fmt("'%s': spectral norm sigma is %g", c.name.c_str(), sigma));
+    } else {
+      w = tensor_data(h, p + ".weight");
+    }
+    const std::vector<float>& b = *tensor_data(h, p + ".bias");
+    const float inv = (float)sigma;
+    const int taps = c.ks * c.ks;
+    // OIHW -> [CoutPad][tap][CinPad]; torch computes weight_orig / sigma in fp32
+    for (int o = 0; o < c.cout; ++o)
+      for (int i = 0; i < c.cin; ++i)
+        for (int t = 0; t < taps; ++t) {
+          const float wv = (*w)[((size_t)o * c.cin + i) * taps + t];
+          blob[c.w_off + ((size_t)o * taps + t) * c.cinp + i] = c.spectral ? wv / inv : wv;
+        }
+    for (int o = 0; o < c.cout; ++o) blob[c.b_off + o] = b[o];
+    if (c.in_affine) {
+      const std::vector<float>& gm = *tensor_data(h, c.name + ".layers.norm.weight");
+      const std::vector<float>& bt = *tensor_data(h, c.name + ".layers.norm.bias");
+      for (int o = 0; o < c.cout; ++o) { blob[c.g_off + o] = gm[o]; blob[c.be_off + o] = bt[o]; }
+    }
+  }
+  // SPADE gamma/beta filters: virtual column pairs [gamma(32) | beta(32)] per 32 virtual channels;
+  // virtual channel v = set*Cp + c, set 0 = conv_block_0/1, set 1 = conv_block_s
+  for (auto& sg : h->spades) {
+    const std::string blk = sg.key.substr(0, sg.key.size() - 2);
+    const std::string which = sg.key.substr(sg.key.size() - 1);
+    const int condp = pad8(sg.cond);
+    for (int set = 0; set < sg.nsets; ++set) {
+      const std::string cn = blk + ".conv_block_" + (set == 0 ? which : std::string("s"));
+      const std::string sp = cn + ".layers.norm.mlps.0.0.layers.conv";
+      const std::vector<float>& w = *tensor_data(h, sp + ".weight");   // [2C][cond]
+      const std::vector<float>& b = *tensor_data(h, sp + ".bias");
+      for (int ch = 0; ch < sg.C; ++ch) {
+        const int v = set * sg.Cp + ch;
+        const int colg = (v / 32) * 64 + (v % 32), colb = colg + 32;
+        for (int k = 0; k < sg.cond; ++k) {
+          blob[sg.w_off + (size_t)colg * condp + k] = w[(size_t)ch * sg.cond + k];              // gamma = first C rows
+          blob[sg.w_off + (size_t)colb * condp + k] = w[(size_t)(sg.C + ch) * sg.cond + k];     // beta = last C rows
+        }
+        blob[sg.b_off + colg] = b[ch];
+        blob[sg.b_off + colb] = b[sg.C + ch];
+      }
+    }
+  }
+  if (h->device < 0) {
+    h->host_blob.swap(blob);
+  } else {
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->weights_ready = true;
+  }
+  for (auto& t : h->tensors) { std::vector<float>().swap(t.data); }   // host copies no longer needed
+  return RIB_OK;
+}
+
+size_t rib_weights_bytes(const rib_handle* h) { return h ? h->blob_floats * sizeof(float) : 0; }
+
+int rib_export_weights(rib_handle* h, void* dst, size_t bytes, void* hip_stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!dst || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_export_weights: size mismatch");
+  HIP_TRY(h, hipMemcpyAsync(dst, h->d_blob, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
+  return RIB_OK;
+}
+
+int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_stream) {
+  if (!h) return RIB_ERR_INVALID;
+  if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
+  HIP_TRY(h, hipMemcpyAsync(h->d_blob, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
+  h->weights_ready = true;
+  return RIB_OK;
+}
+
+size_t rib_workspace_bytes(rib_handle* h, int B, int H, int W) {
+  if (!h) return 0;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P) return 0;
+  // + scratch img/mask frames rib_chain uses when the caller does not ask for them
+  return P->ws_bytes + 2 * align256((size_t)B * h->g.c.image_nc * H * W * sizeof(float)) +
+         align256((size_t)B * H * W * sizeof(float));
+}
+
+int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
+                const float* img_prev, float* img, float* mask, void* workspace, size_t workspace_bytes,
+                void* hip_stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!label || !img_fake || !img_prev || !img || !mask || !workspace) return fail(h, RIB_ERR_INVALID, "rib_forward: null pointer");
+  Plan* P = get_plan(h, B, H, W);
+  if (!P) return RIB_ERR_INVALID;
+  if (workspace_bytes < P->ws_bytes) return fail(h, RIB_ERR_WORKSPACE, fmt("workspace %zu < required %zu bytes", workspace_bytes, P->ws_bytes));
+  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
+  R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
+  return run_plan(h, P, R, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const float* mask,
+              const float* dain, float* fuse, void* hip_stream) {
+  if (!h || !img || !mask || !dain || !fuse) return RIB_ERR_INVALID;
+  const size_t total = (size_t)B * C * H * W;
+  const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_blend, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, mask, dain, fuse, C, H * W, total);
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, uint8_t* out, void* hip_stream) {
+  if (!h || !img || !out) return RIB_ERR_INVALID;
+  const size_t total = (size_t)B * C * H * W;
+  const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, out, C, H * W, total);
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const float* flow, float* out, void* hip_stream) {
+  if (!h || !img || !flow || !out) return RIB_ERR_INVALID;
+  hipLaunchKernelGGL(k_warp, dim3((H * W + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W);
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame, const float* labels,
+              const float* dains, float* imgs, float* masks, float* fuses, void* workspace,
+              size_t workspace_bytes, void* hip_stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (T < 1 || !key_frame || !labels || !dains || !fuses || !workspace) return fail(h, RIB_ERR_INVALID, "rib_chain: bad argument");
+  Plan* P = get_plan(h, B, H, W);
+  if (!P) return RIB_ERR_INVALID;
+  const rib_config& c = h->g.c;
+  const size_t frame = (size_t)B * c.image_nc * H * W, mframe = (size_t)B * H * W, lframe = (size_t)B * c.label_nc * H * W;
+  const size_t need = P->ws_bytes + 2 * align256(frame * sizeof(float)) + align256(mframe * sizeof(float));
+  if (workspace_bytes < need) return fail(h, RIB_ERR_WORKSPACE, fmt("workspace %zu < required %zu bytes", workspace_bytes, need));
+  char* wsb = reinterpret_cast<char*>(workspace);
+  float* tmp_img = reinterpret_cast<float*>(wsb + P->ws_bytes);
+  float* tmp_mask = reinterpret_cast<float*>(wsb + P->ws_bytes + align256(frame * sizeof(float)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const float* prev = key_frame;   // evaluator.py:240-244: a segment starts from the ground-truth key frame
+  for (int t = 0; t < T; ++t) {
+    float* img_t = imgs ? imgs + (size_t)t * frame : tmp_img;
+    float* mask_t = masks ? masks + (size_t)t * mframe : tmp_mask;
+    float* fuse_t = fuses + (size_t)t * frame;
+    Resolver R; R.ws = wsb; R.blob = h->d_blob;
+    R.user[U_LABEL] = labels + (size_t)t * lframe; R.user[U_FAKE] = dains + (size_t)t * frame; R.user[U_PREV] = prev;
+    R.user[U_IMG] = img_t; R.user[U_MASK] = mask_t;
+    rc = run_plan(h, P, R, st);
+    if (rc) return rc;
+    rc = rib_blend(h, B, c.image_nc, H, W, img_t, mask_t, dains + (size_t)t * frame, fuse_t, hip_stream);
+    if (rc) return rc;
+    prev = fuse_t;                 // evaluator.py:252: prev_img = results['fuse'][-1]
+  }
+  return RIB_OK;
+}
+
+int rib_num_taps(rib_handle* h, int B, int H, int W) {
+  if (!h) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  return P ? (int)P->taps.size() : RIB_ERR_INVALID;
+}
+
+int rib_tap_info(rib_handle* h, int B, int H, int W, int idx, const char** name, int* C, int* th, int* tw) {
+  if (!h) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P || idx < 0 || idx >= (int)P->taps.size()) return RIB_ERR_INVALID;
+  const Tap& t = P->taps[idx];
+  if (name) *name = t.name.c_str();
+  if (C) *C = t.C;
+  if (th) *th = t.H;
+  if (tw) *tw = t.W;
+  return RIB_OK;
+}
+
+int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* workspace, float* dst, void* hip_stream) {
+  if (!h || !workspace || !dst) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P || idx < 0 || idx >= (int)P->taps.size()) return RIB_ERR_INVALID;
+  const Tap& t = P->taps[idx];
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + t.off);
+  hipLaunchKernelGGL(k_unpack, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(st));
+  return RIB_OK;
+}
+
+// Inverse of the filter re-layout, from a host-only handle: used by the CPU tests to check the
+// spectral-norm fold and the [CoutPad][tap][CinPad] / SPADE column layouts against the oracle.
+int rib_debug_conv_weight(rib_handle* h, const char* conv_name, float* w_oihw, float* bias) {
+  if (!h || !conv_name || !w_oihw || !bias) return RIB_ERR_INVALID;
+  if (h->host_blob.empty()) return fail(h, RIB_ERR_STATE, "rib_debug_conv_weight needs a finalized host-only handle (device < 0)");
+  auto it = h->conv_index.find(conv_name);
+  if (it == h->conv_index.end() || !h->convs[it->second].used) return fail(h, RIB_ERR_INVALID, fmt("unknown conv '%s'", conv_name));
+  const ConvDef& c = h->convs[it->second];
+  const int taps = c.ks * c.ks;
+  for (int o = 0; o < c.cout; ++o) {
+    for (int i = 0; i < c.cin; ++i)
+      for (int t = 0; t < taps; ++t)
+        w_oihw[((size_t)o * c.cin + i) * taps + t] = h->host_blob[c.w_off + ((size_t)o * taps + t) * c.cinp + i];
+    bias[o] = h->host_blob[c.b_off + o];
+  }
+  return RIB_OK;
+}
+
+int rib_debug_spade_weight(rib_handle* h, const char* conv_name, float* w_2c_by_cond, float* bias_2c) {
+  if (!h || !conv_name || !w_2c_by_cond || !bias_2c) return RIB_ERR_INVALID;
+  if (h->host_blob.empty()) return fail(h, RIB_ERR_STATE, "rib_debug_spade_weight needs a finalized host-only handle (device < 0)");
+  const std::string cn = conv_name;
+  const size_t pos = cn.rfind(".conv_block_");
+  if (pos == std::string::npos) return fail(h, RIB_ERR_INVALID, "not a SPADE conv block");
+  const std::string blk = cn.substr(0, pos), which = cn.substr(cn.size() - 1);
+  const std::string key = blk + "." + (which == "s" ? std::string("0") : which);
+  auto it = h->spade_index.find(key);
+  if (it == h->spade_index.end()) return fail(h, RIB_ERR_INVALID, fmt("no SPADE group '%s'", key.c_str()));
+  const SpadeGroup& sg = h->spades[it->second];
+  const int set = which == "s" ? 1 : 0;
+  const int condp = pad8(sg.cond);
+  for (int ch = 0; ch < sg.C; ++ch) {
+    const int v = set * sg.Cp + ch;
+    const int colg = (v / 32) * 64 + (v % 32), colb = colg + 32;
+    for (int k = 0; k < sg.cond; ++k) {
+      w_2c_by_cond[(size_t)ch * sg.cond + k] = h->host_blob[sg.w_off + (size_t)colg * condp + k];
+      w_2c_by_cond[(size_t)(sg.C + ch) * sg.cond + k] = h->host_blob[sg.w_off + (size_t)colb * condp + k];
+    }
+    bias_2c[ch] = h->host_blob[sg.b_off + colg];
+    bias_2c[sg.C + ch] = h->host_blob[sg.b_off + colb];
+  }
+  return RIB_OK;
+}
+
+// Launch list of a plan, for the CPU-side structure tests: "<name>|<kernel class>|<grid>|<tile>"
+int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf, size_t buflen) {
+  if (!h || !buf) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
+  const Op& op = P->ops[idx];
+  if (op.kind == OP_IGEMM)
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.flops);
+  else
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
+  return RIB_OK;
+}
+
+int rib_profile_begin(rib_handle* h) {
+  if (!h) return RIB_ERR_INVALID;
+  for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+  h->prof_events.clear();
+  h->profiling = true;
+  return RIB_OK;
+}
+
+int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms[RIB_KC_COUNT]) {
+  if (!h || !launches || !ms) return RIB_ERR_INVALID;
+  h->profiling = false;
+  for (int i = 0; i < RIB_KC_COUNT; ++i) { launches[i] = 0; ms[i] = 0.0; }
+  for (auto& pe : h->prof_events) {
+    HIP_TRY(h, hipEventSynchronize(pe.second.second));
+    float t = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&t, pe.second.first, pe.second.second));
+    launches[pe.first] += 1; ms[pe.first] += (double)t;
+    (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second);
+  }
+  h->prof_events.clear();
+  return RIB_OK;
+}
+
+int rib_forward_flops(rib_handle* h, int B, int H, int W, double flops[RIB_KC_COUNT]) {
+  if (!h || !flops) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P) return RIB_ERR_INVALID;
+  for (int i = 0; i < RIB_KC_COUNT; ++i) flops[i] = P->flops[i];
+  return RIB_OK;
+}
+
+int rib_num_launches(rib_handle* h, int B, int H, int W) {
+  if (!h) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  return P ? (int)P->ops.size() : RIB_ERR_INVALID;
+}
+
+}  // extern "C"

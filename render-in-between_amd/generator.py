@@ -1,0 +1,256 @@
+"""Drop-in host-side mirror of the reference ``Generator`` object protocol
+(PGNR/models/generator.py:35-234 as used by PGNR/models/trainer.py:61,67 and
+PGNR/models/evaluator.py:170,255):
+
+    net_G = Generator(cfg.gen)            # same ctor argument
+    net_G.load_state_dict(state_dict)     # same 372-tensor checkpoint, strict
+    net_G.eval()
+    img, mask = net_G(label, label_prev, img_fake, img_prev)
+
+All compute happens in hand-written HIP kernels behind the C ABI of
+include/rib.h; this class only validates arguments, owns the workspace tensor
+and passes device pointers.  No CPU fallback exists: constructing a Generator
+without a GPU or without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _native
+from .config import GenSpec
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Generator:
+    def __init__(self, gen_cfg, device=None):
+        self.spec = GenSpec.from_cfg(gen_cfg)
+        self.gen_cfg = gen_cfg
+        if not torch.cuda.is_available():
+            raise RuntimeError("render_in_between_amd.Generator needs a ROCm GPU (MI355X); "
+                               "there is no CPU path")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Generator device must be a GPU, got %s" % (self.device,))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._lib = _native.lib()
+        s = self.spec
+        cfg = _native.RibConfig(
+            label_nc=s.label_nc, image_nc=s.image_nc, num_filters=s.num_filters,
+            max_num_filters=s.max_num_filters, num_layers=s.num_layers,
+            num_down_img=s.num_down_img, emb_filters=s.emb_filters,
+            emb_max_filters=s.emb_max_filters, emb_down=s.emb_down,
+            mask_filters=s.mask_filters, mask_max_filters=s.mask_max_filters,
+            mask_down=s.mask_down, mask_res_blocks=s.mask_res_blocks)
+        h = C.c_void_p()
+        rc = self._lib.rib_create(C.byref(cfg), self.device.index, C.byref(h))
+        if rc != 0:
+            msg = self._lib.rib_last_error(None)
+            raise (NotImplementedError if rc == -2 else _native.RibError)(
+                *(("rib_create: " + msg.decode(),) if rc == -2 else (rc, msg.decode())))
+        self._h = h
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.training = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.rib_destroy(h)
+            self._h = None
+
+    # ---- nn.Module-protocol no-ops the reference driver calls ----------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the MI355X path is inference-only")
+        return self.eval()
+
+    def to(self, device=None, *a, **k):
+        if device is not None and torch.device(device).type == "cuda":
+            idx = torch.device(device).index
+            if idx is not None and idx != self.device.index:
+                raise RuntimeError("a Generator handle is bound to one GPU; construct it on %s" % device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    # ---- checkpoint surface ---------------------------------------------------------------
+    def expected_tensors(self):
+        """[(name, shape, used)] exactly as the native loader expects them."""
+        out = []
+        name = C.c_char_p(); ndim = C.c_int(); dims = (C.c_int64 * 4)(); used = C.c_int()
+        for i in range(self._lib.rib_num_tensors(self._h)):
+            _native.check(self._h, self._lib.rib_tensor_info(self._h, i, C.byref(name), C.byref(ndim), dims, C.byref(used)))
+            out.append((name.value.decode(), tuple(dims[j] for j in range(ndim.value)), bool(used.value)))
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Same contract as nn.Module.load_state_dict(strict=True) on the
+        reference generator (PGNR/utils/utils.py:107-119): every reference key
+        must be present with its shape; unknown keys are an error."""
+        if "state_dict" in state_dict and not torch.is_tensor(state_dict["state_dict"]):
+            state_dict = state_dict["state_dict"]                      # utils.py:115-116
+        sd = {k.replace("module.", ""): v for k, v in state_dict.items()}   # utils.py:101-105
+        expected = {n for n, _, _ in self.expected_tensors()}
+        if strict:
+            missing = sorted(expected - set(sd))
+            unexpected = sorted(set(sd) - expected)
+            if missing or unexpected:
+                raise RuntimeError("Error(s) in loading state_dict for Generator:\n\tMissing key(s): %s\n\t"
+                                   "Unexpected key(s): %s" % (missing[:8], unexpected[:8]))
+        for k, v in sd.items():
+            if k not in expected:
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            dims = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _native.check(self._h, self._lib.rib_set_tensor(self._h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), dims))
+        with torch.cuda.device(self.device):
+            _native.check(self._h, self._lib.rib_finalize_weights(self._h))
+        return self
+
+    # ---- multi-GPU weight hand-off (one RCCL broadcast of the folded blob) -----------------
+    def export_weights(self) -> torch.Tensor:
+        n = self._lib.rib_weights_bytes(self._h)
+        buf = torch.empty(n // 4, dtype=torch.float32, device=self.device)
+        _native.check(self._h, self._lib.rib_export_weights(self._h, _ptr(buf), n, self._stream()))
+        return buf
+
+    def weights_numel(self) -> int:
+        return self._lib.rib_weights_bytes(self._h) // 4
+
+    def import_weights(self, buf: torch.Tensor):
+        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        _native.check(self._h, self._lib.rib_import_weights(self._h, _ptr(buf), buf.numel() * 4, self._stream()))
+        return self
+
+    # ---- forward ----------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, B, H, W):
+        key = (B, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = self._lib.rib_workspace_bytes(self._h, B, H, W)
+            if n == 0:
+                _native.check(self._h, -1)
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _prep(self, t, ch, name, shape=None):
+        if not torch.is_tensor(t) or t.dim() != 4 or t.shape[1] != ch:
+            raise ValueError("%s must be a [B,%d,H,W] tensor, got %s" % (name, ch, tuple(getattr(t, "shape", ()))))
+        if shape is not None and (t.shape[0], t.shape[2], t.shape[3]) != shape:
+            raise ValueError("%s has shape %s, expected B,H,W = %s" % (name, tuple(t.shape), shape))
+        if t.device != self.device:
+            t = t.to(self.device)
+        return t.to(torch.float32).contiguous()
+
+    def __call__(self, label, label_prev, img_fake, img_prev):
+        """img_final, mask = G(label, label_prev, img_fake, img_prev)
+        (generator.py:181-234).  ``label_prev`` is accepted and ignored — the
+        reference never reads it; it may be None."""
+        s = self.spec
+        label = self._prep(label, s.label_nc, "label")
+        B, _, H, W = label.shape
+        img_fake = self._prep(img_fake, s.image_nc, "img_fake", (B, H, W))
+        img_prev = self._prep(img_prev, s.image_nc, "img_prev", (B, H, W))
+        ws = self._workspace(B, H, W)
+        img = torch.empty((B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._h, self._lib.rib_forward(
+                self._h, B, H, W, _ptr(label), _ptr(img_fake), _ptr(img_prev), _ptr(img), _ptr(mask),
+                _ptr(ws), ws.numel(), self._stream()))
+        return img, mask
+
+    forward = __call__
+
+    def chain(self, key_frame, labels, dains, want_all=True):
+        """One autoregressive segment on device (evaluator.py:238-262):
+        labels [T,B,label_nc,H,W], dains [T,B,image_nc,H,W], key_frame
+        [B,image_nc,H,W] -> (imgs, masks, fuses); prev never leaves HBM."""
+        s = self.spec
+        T = labels.shape[0]
+        B, H, W = labels.shape[1], labels.shape[3], labels.shape[4]
+        labels = labels.to(self.device, torch.float32).contiguous()
+        dains = dains.to(self.device, torch.float32).contiguous()
+        key_frame = self._prep(key_frame, s.image_nc, "key_frame", (B, H, W))
+        assert labels.shape == (T, B, s.label_nc, H, W) and dains.shape == (T, B, s.image_nc, H, W)
+        ws = self._workspace(B, H, W)
+        fuses = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
+        imgs = torch.empty_like(fuses) if want_all else None
+        masks = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=self.device) if want_all else None
+        with torch.cuda.device(self.device):
+            _native.check(self._h, self._lib.rib_chain(
+                self._h, T, B, H, W, _ptr(key_frame), _ptr(labels), _ptr(dains), _ptr(imgs), _ptr(masks),
+                _ptr(fuses), _ptr(ws), ws.numel(), self._stream()))
+        return imgs, masks, fuses
+
+    # ---- driver-side ops ----------------------------------------------------------------------
+    def blend(self, img, mask, dain):
+        img = img.to(self.device, torch.float32).contiguous(); mask = mask.to(self.device, torch.float32).contiguous()
+        dain = dain.to(self.device, torch.float32).contiguous()
+        B, Cc, H, W = img.shape
+        out = torch.empty_like(img)
+        _native.check(self._h, self._lib.rib_blend(self._h, B, Cc, H, W, _ptr(img), _ptr(mask), _ptr(dain), _ptr(out), self._stream()))
+        return out
+
+    def quantise(self, img):
+        img = img.to(self.device, torch.float32).contiguous()
+        B, Cc, H, W = img.shape
+        out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=self.device)
+        _native.check(self._h, self._lib.rib_quantise(self._h, B, Cc, H, W, _ptr(img), _ptr(out), self._stream()))
+        return out
+
+    def warp(self, img, flow):
+        img = img.to(self.device, torch.float32).contiguous(); flow = flow.to(self.device, torch.float32).contiguous()
+        B, Cc, H, W = img.shape
+        assert flow.shape == (B, 2, H, W)
+        out = torch.empty_like(img)
+        _native.check(self._h, self._lib.rib_warp(self._h, B, Cc, H, W, _ptr(img), _ptr(flow), _ptr(out), self._stream()))
+        return out
+
+    # ---- introspection / measurement -----------------------------------------------------------
+    def read_taps(self, B, H, W):
+        """Intermediate activations of the LAST forward at this shape, as NCHW CPU tensors."""
+        ws = self._workspace(B, H, W)
+        out = {}
+        name = C.c_char_p(); ch = C.c_int(); th = C.c_int(); tw = C.c_int()
+        for i in range(self._lib.rib_num_taps(self._h, B, H, W)):
+            _native.check(self._h, self._lib.rib_tap_info(self._h, B, H, W, i, C.byref(name), C.byref(ch), C.byref(th), C.byref(tw)))
+            dst = torch.empty((B, ch.value, th.value, tw.value), dtype=torch.float32, device=self.device)
+            _native.check(self._h, self._lib.rib_read_tap(self._h, B, H, W, i, _ptr(ws), _ptr(dst), self._stream()))
+            out[name.value.decode()] = dst.cpu()
+        return out
+
+    def profile_begin(self):
+        _native.check(self._h, self._lib.rib_profile_begin(self._h))
+
+    def profile_collect(self):
+        n = len(_native.KC_NAMES)
+        launches = (C.c_int64 * n)(); ms = (C.c_double * n)()
+        _native.check(self._h, self._lib.rib_profile_collect(self._h, launches, ms))
+        return {k: {"launches": int(launches[i]), "ms": float(ms[i])} for i, k in enumerate(_native.KC_NAMES)}
+
+    def forward_flops(self, B, H, W):
+        n = len(_native.KC_NAMES)
+        fl = (C.c_double * n)()
+        _native.check(self._h, self._lib.rib_forward_flops(self._h, B, H, W, fl))
+        return {k: float(fl[i]) for i, k in enumerate(_native.KC_NAMES)}
+
+    def num_launches(self, B, H, W):
+        return self._lib.rib_num_launches(self._h, B, H, W)

@@ -27,9 +27,11 @@ from oracle import generator_ref, ref_import             # noqa: E402
 
 ORACLE_TOL = 1e-5
 
-SMALL_CFG = dict(num_filters=4, max_num_filters=32,
-                 mask=dict(num_filters=8, max_num_filters=32),
-                 embed=dict(num_filters=8, max_num_filters=32))
+# a narrow variant of HSM.yaml's gen block that keeps every structural feature (learned and
+# identity shortcuts, 5 cond levels, stride-2 encoders) with at most 64 channels
+SMALL_CFG = dict(num_filters=16, max_num_filters=64,
+                 mask=dict(num_filters=32, max_num_filters=64),
+                 embed=dict(num_filters=32, max_num_filters=64))
 
 
 def summary(t):
@@ -87,7 +89,7 @@ def main():
 
     # shrunken config with per-layer taps from forward hooks on the reference
     small = rib.hsm_gen_config(**SMALL_CFG)
-    spec, sd, G = run_case("small_64", small, 7, 1, 64, 64, 1, report)
+    spec, sd, G = run_case("mid_64", small, 7, 1, 64, 64, 1, report)
     label, fake, prev = synth.make_inputs(spec, 1, 64, 64, 7)
     taps = {}
     hooks = []
@@ -98,7 +100,11 @@ def main():
             + ["up_%d" % i for i in range(spec.num_down_img + 1)]
             + ["flow_network_temp.res_flow.%d" % i for i in range(spec.mask_res_blocks)]
             + ["flow_network_temp.down_lbl", "flow_network_temp.down_img",
-               "flow_network_temp.up_flow"])
+               "flow_network_temp.up_flow"]
+            + ["%s_%d.conv_block_0" % (k, i) for k in ("down", "up") for i in range(spec.num_down_img + 1)]
+            + ["flow_network_temp.down_lbl.%d.layers.conv" % i for i in range(spec.mask_down)]
+            + ["flow_network_temp.down_img.%d.layers.conv" % i for i in range(spec.mask_down)]
+            + ["flow_network_temp.up_flow.%d.layers.conv" % (2 * j + 1) for j in range(spec.mask_down)])
     mods = dict(G.named_modules())
     for n in want:
         hooks.append(mods[n].register_forward_hook(
@@ -118,14 +124,26 @@ def main():
     for i in range(spec.mask_res_blocks):
         pairs["flow_network_temp.res_flow.%d" % i] = "mask.res_%d" % i
     pairs["flow_network_temp.up_flow"] = "mask.up_%d" % (spec.mask_down - 1)
+    for k in ("down", "up"):
+        for i in range(spec.num_down_img + 1):
+            pairs["%s_%d.conv_block_0" % (k, i)] = "%s_%d.h" % (k, i)
+    for i in range(spec.mask_down):
+        pairs["flow_network_temp.down_lbl.%d.layers.conv" % i] = "mask.lbl_%d.raw" % i
+        pairs["flow_network_temp.down_img.%d.layers.conv" % i] = "mask.img_%d.raw" % i
+    for j in range(spec.mask_down):
+        pairs["flow_network_temp.up_flow.%d.layers.conv" % (2 * j + 1)] = "mask.up_%d.raw" % j
+    with open(os.path.join(HERE, "mid_64_tap_names.json"), "w") as f:
+        json.dump(pairs, f, indent=0, sort_keys=True)
     worst = 0.0
     for rn, on in pairs.items():
         d = float((taps[rn] - otaps[on]).abs().max())
         worst = max(worst, d)
         assert d <= ORACLE_TOL * max(1.0, float(taps[rn].abs().max())), (rn, d)
-    report["small_64"]["taps_oracle_vs_reference_max"] = worst
-    np.savez_compressed(os.path.join(HERE, "small_64_taps.npz"),
-                        **{k.replace(".", "__"): v.numpy() for k, v in taps.items()})
+    report["mid_64"]["taps_oracle_vs_reference_max"] = worst
+    # maps of 32x32 and larger are stored at every 2nd pixel to keep the fixture small
+    np.savez_compressed(os.path.join(HERE, "mid_64_taps.npz"),
+                        **{k.replace(".", "__"): (v[:, :, ::2, ::2] if v.shape[-1] >= 32 else v).numpy()
+                           for k, v in taps.items()})
 
     # 3-step autoregressive chain @128 (driver semantics, evaluator.py:238-266),
     # driven through the REFERENCE generator

@@ -1,0 +1,155 @@
+"""CPU suite for the native library: the C ABI loads and exports every symbol
+of include/rib.h, and the host-side logic (layer inventory, spectral-norm fold,
+filter re-layout, launch plans) agrees with the build's Python spec and with
+the oracle.  No compute entry point is called (there is no GPU here); the
+handle is created host-only (device = -1)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import render_in_between_amd as rib
+from render_in_between_amd import _native, synth
+from oracle import generator_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = [n for n, _ in _native.RibConfig._fields_]
+MID_CFG = dict(num_filters=16, max_num_filters=64,
+               mask=dict(num_filters=32, max_num_filters=64),
+               embed=dict(num_filters=32, max_num_filters=64))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_native.LIB_PATH):
+        from importlib import util
+        spec = util.spec_from_file_location("rib_build", os.path.join(os.path.dirname(_native.LIB_PATH), "build.py"))
+        mod = util.module_from_spec(spec); spec.loader.exec_module(mod)
+        mod.build()
+    return _native.lib()
+
+
+def host_handle(lib, cfg):
+    spec = rib.GenSpec.from_cfg(cfg)
+    c = _native.RibConfig(**{n: getattr(spec, n) for n in FIELDS})
+    h = C.c_void_p()
+    rc = lib.rib_create(C.byref(c), -1, C.byref(h))
+    assert rc == 0, lib.rib_last_error(None)
+    return spec, h
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "rib.h")).read()
+    declared = set(re.findall(r"\b(rib_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "librib.so does not export %s" % name
+        assert name in _native.SIGNATURES, "no ctypes signature for %s" % name
+    assert set(_native.SIGNATURES) == declared
+    # the struct the binding passes matches the header field for field
+    fields = re.findall(r"int32_t\s+(\w+);", hdr)
+    assert fields == FIELDS
+
+
+def test_native_inventory_matches_python_spec(lib):
+    spec, h = host_handle(lib, rib.hsm_gen_config())
+    want = dict(rib.state_dict_spec(spec))
+    name = C.c_char_p(); ndim = C.c_int(); dims = (C.c_int64 * 4)(); used = C.c_int()
+    got = {}
+    for i in range(lib.rib_num_tensors(h)):
+        assert lib.rib_tensor_info(h, i, C.byref(name), C.byref(ndim), dims, C.byref(used)) == 0
+        got[name.value.decode()] = (tuple(dims[j] for j in range(ndim.value)), bool(used.value))
+    assert len(got) == 372 and set(got) == set(want)
+    for k, (shape, used_) in got.items():
+        assert shape == want[k], k
+        assert used_ == (not k.startswith(("label_embedding.", "conv_mask."))), k
+    lib.rib_destroy(h)
+
+
+def test_strict_load_errors(lib):
+    spec, h = host_handle(lib, rib.hsm_gen_config(**MID_CFG))
+    assert lib.rib_finalize_weights(h) == -4                      # RIB_ERR_MISSING
+    assert b"missing key" in lib.rib_last_error(h)
+    x = np.zeros(4, np.float32)
+    d = (C.c_int64 * 1)(4)
+    assert lib.rib_set_tensor(h, b"no.such.tensor", x.ctypes.data_as(C.c_void_p), 1, d) == -1
+    assert b"unexpected key" in lib.rib_last_error(h)
+    assert lib.rib_set_tensor(h, b"down_first.layers.conv.bias", x.ctypes.data_as(C.c_void_p), 1, d) == -1
+    assert b"size mismatch" in lib.rib_last_error(h)
+    lib.rib_destroy(h)
+
+
+@pytest.mark.parametrize("cfgname", ["mid", "full"])
+def test_fold_and_layout_match_oracle(lib, cfgname):
+    cfg = rib.hsm_gen_config(**MID_CFG) if cfgname == "mid" else rib.hsm_gen_config()
+    spec, h = host_handle(lib, cfg)
+    sd = synth.make_state_dict(spec, 21)
+    for k, v in sd.items():
+        t = v.contiguous()
+        d = (C.c_int64 * t.dim())(*t.shape)
+        assert lib.rib_set_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), d) == 0, lib.rib_last_error(h)
+    assert lib.rib_finalize_weights(h) == 0, lib.rib_last_error(h)
+    convs = [c for c in rib.conv_inventory(spec) if c.used]
+    if cfgname == "full":   # a sample keeps the full-size case quick
+        convs = [c for c in convs if c.name in ("ref_embedding.down_3", "down_first", "up_4.conv_block_s",
+                                                "res_1.conv_block_1", "down_0.conv_block_0", "down_0.conv_block_s",
+                                                "flow_network_temp.res_flow.0.conv_block_0", "conv_img")]
+    for c in convs:
+        w_ref, b_ref = generator_ref.conv_weight(sd, c.name)
+        w = np.empty(tuple(w_ref.shape), np.float32); b = np.empty(c.cout, np.float32)
+        assert lib.rib_debug_conv_weight(h, c.name.encode(), w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+        scale = float(w_ref.abs().max())
+        assert np.abs(w - w_ref.numpy()).max() <= 2e-6 * scale, c.name      # fp64 vs fp32 sigma
+        assert np.array_equal(b, b_ref.numpy()), c.name
+        if c.spade_cond:
+            p = c.name + ".layers.norm.mlps.0.0.layers.conv"
+            ws = np.empty((2 * c.cin, c.spade_cond), np.float32); bs = np.empty(2 * c.cin, np.float32)
+            assert lib.rib_debug_spade_weight(h, c.name.encode(), ws.ctypes.data_as(C.c_void_p), bs.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(ws, sd[p + ".weight"].numpy().reshape(2 * c.cin, c.spade_cond)), c.name
+            assert np.array_equal(bs, sd[p + ".bias"].numpy()), c.name
+    lib.rib_destroy(h)
+
+
+def test_plan_flops_and_shape_rules(lib):
+    spec, h = host_handle(lib, rib.hsm_gen_config())
+    fl = (C.c_double * 6)()
+    for (B, H, W) in [(1, 512, 512), (1, 320, 480), (2, 64, 64), (4, 1024, 1024)]:
+        assert lib.rib_forward_flops(h, B, H, W, fl) == 0, lib.rib_last_error(h)
+        assert abs(sum(fl) - B * rib.conv_flops(spec, H, W)) < 1e-6 * sum(fl)
+        assert lib.rib_workspace_bytes(h, B, H, W) > 0
+    assert abs(sum(fl) / 4 / 1e9 - 926.4) < 0.1                     # SURVEY §8d, 1024^2 per sample
+    assert lib.rib_num_launches(h, 1, 512, 512) > 100
+    # sizes not divisible by 16 are rejected (the reference itself fails on them)
+    assert lib.rib_workspace_bytes(h, 1, 250, 250) == 0
+    assert b"multiples of 16" in lib.rib_last_error(h)
+    # every launch of the plan is describable and every grid is non-empty
+    buf = C.create_string_buffer(512)
+    n = lib.rib_num_launches(h, 1, 512, 512)
+    names = []
+    for i in range(n):
+        assert lib.rib_debug_launch_info(h, 1, 512, 512, i, buf, 512) == 0
+        name, kclass, grid, _, _ = buf.value.decode().split("|")
+        assert all(int(g) > 0 for g in grid.split(","))
+        names.append(name)
+    for must in ("down_0.0.spade", "res_1.conv_block_1", "up_0.conv_block_s", "conv_img",
+                 "flow_network_temp.res_flow.3.join", "flow_network_temp.conv_mask.0"):
+        assert must in names
+    lib.rib_destroy(h)
+
+
+def test_unsupported_configs_fail_loudly(lib):
+    spec = rib.GenSpec.from_cfg(rib.hsm_gen_config(embed=dict(num_filters=24)))
+    c = _native.RibConfig(**{n: getattr(spec, n) for n in FIELDS})
+    h = C.c_void_p()
+    assert lib.rib_create(C.byref(c), -1, C.byref(h)) == -2
+    assert b"multiple of 32" in lib.rib_last_error(None)
+
+
+def test_generator_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rib.Generator(rib.hsm_gen_config())
