@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3)
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,6 +79,11 @@ def main():
         img, mask = G(label, None, fake, prev)
         return G.blend(img, mask, fake)
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    log("weights ready, warming up")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -104,6 +110,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
+    log("timed region done: %.3f ms/step" % ms_per_step)
     # ---- roofline of the dominant kernel class: profiling pass (not in the timed region) ----
     flops = G.forward_flops(B, H, W)
     G.profile_begin()
@@ -127,6 +134,7 @@ def main():
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
     }
 
+    log("profile pass done: conv %.3f ms/step" % conv_ms)
     # ---- parity on the bench inputs + CPU baseline (oracle timed on the host cores) ----
     cpu = None
     parity = None
@@ -136,6 +144,7 @@ def main():
         torch.set_num_threads(os.cpu_count() or 1)
         lc, fc, pc = label.cpu(), fake.cpu(), prev.cpu()
         oimg, omask = R(lc, None, fc, pc)                       # warm-up + parity reference
+        log("cpu oracle warm-up frame done (%d threads)" % torch.get_num_threads())
         img, mask = G(label, None, fake, prev)
         parity = {"max_abs_img": float((img.cpu() - oimg).abs().max()),
                   "max_abs_mask": float((mask.cpu() - omask).abs().max()), "tolerance": 1e-3}

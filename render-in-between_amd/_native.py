@@ -73,6 +73,11 @@ def lib():
             raise RuntimeError(
                 "native library %s is missing: build it with "
                 "`python render-in-between_amd/csrc/build.py` (there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the
+        # one already mapped when librib.so resolves its libamdhip64 dependency: with the system
+        # runtime loaded first the process ends up with two HIP runtimes and the second one
+        # reports "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

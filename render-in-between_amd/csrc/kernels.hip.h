@@ -62,7 +62,7 @@ struct IgemmParams {
   int yC, yoff, Cout;    // Cout = valid output channels
   int act;
   const float* res;      // residual added before act/store, [B][Hout][Wout][resC] or nullptr
-  int resC;
+  int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
   float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
   // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
           if (cvalid && oy < p.Hout && ox < p.Wout) {
             const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
             float v = acc[mf][nf][r] + bv;
-            if (p.res) v += p.res[pix * p.resC + col];
+            if (p.res) {
+              const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : pix;
+              v += p.res[rpix * p.resC + col];
+            }
             v = apply_act(v, p.act);
             p.y[pix * p.yC + p.yoff + col] = v;
             if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = v;

@@ -394,7 +394,7 @@ struct Builder {
     Act out; int yoff = 0;  // destination buffer and channel offset
     int cout_store = -1;    // columns stored (default: out slice padded width)
     int act = ACT_NONE;
-    const Act* res = nullptr;
+    const Act* res = nullptr; bool res_ups = false;
     PRef y_nchw;            // optional NCHW copy
     PRef y_user;            // when set, y is this user tensor (yC = cout exactly)
     bool want_stats = false;
@@ -429,7 +429,7 @@ struct Builder {
       p.Cout = a.cout_store >= 0 ? a.cout_store : pad8(c.cout);
       if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
     }
-    if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; }
+    if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
     const int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
@@ -505,9 +505,10 @@ struct Builder {
       outs = act(cs.cout, Hout, Wout);
       ConvArgs a; a.cd = &cs; a.in = ys1; a.out = outs;
       if (!conv(a, name + ".conv_block_s")) return false;
-    } else if (x_ups) { error = name + ": identity shortcut on an upsampled input"; return false; }
+    }
     *out = act(c1.cout, Hout, Wout);
     { ConvArgs a; a.cd = &c1; a.in = y1; a.out = *out; a.res = learned ? &outs : &x;
+      a.res_ups = !learned && x_ups;   // identity shortcut of an upsampled input: x_up[y][x] = x[y>>1][x>>1]
       if (nout) { *nout = norm(out->Cp); a.want_stats = true; a.stats_out = nout; }
       if (!conv(a, name + ".conv_block_1")) return false; }
     tap(name, *out);
