@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Join a rocprofv3 --kernel-trace CSV with the launch plan: per-op device time.
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python3 tools/prof_ops.py --run
+    python3 tools/prof_ops.py --report gpurun_out/prof > gpurun_out/prof_ops.txt
+
+--run executes W warm-up and K timed forward+blend steps (nothing else launches
+kernels), so dispatches map onto plan ops by position.
+"""
+import argparse
+import csv
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def plan_names(B, H, W):
+    import render_in_between_amd as rib
+    from render_in_between_amd import _native
+    lib = _native.lib()
+    spec = rib.GenSpec.from_cfg(rib.hsm_gen_config())
+    c = _native.RibConfig(**{n: getattr(spec, n) for n, _ in _native.RibConfig._fields_})
+    h = C.c_void_p()
+    assert lib.rib_create(C.byref(c), -1, C.byref(h)) == 0
+    buf = C.create_string_buffer(512)
+    out = []
+    for i in range(lib.rib_num_launches(h, B, H, W)):
+        lib.rib_debug_launch_info(h, B, H, W, i, buf, 512)
+        name, kclass, grid, tile, flops = buf.value.decode().split("|")
+        out.append({"name": name, "class": int(kclass), "grid": grid, "tile": tile, "flops": float(flops)})
+    out.append({"name": "blend", "class": 4, "grid": "", "tile": "", "flops": 0.0})
+    return out
+
+
+def run(args):
+    import torch
+    import render_in_between_amd as rib
+    from render_in_between_amd import synth
+    cfg = rib.hsm_gen_config()
+    spec = rib.GenSpec.from_cfg(cfg)
+    G = rib.Generator(cfg).eval()
+    G.load_state_dict(synth.make_state_dict(spec, 0))
+    label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, args.batch, args.size, args.size, 0)]
+    torch.cuda.synchronize()
+    for _ in range(args.warmup + args.steps):
+        img, mask = G(label, None, fake, prev)
+        G.blend(img, mask, fake)
+    torch.cuda.synchronize()
+
+
+def report(args):
+    files = glob.glob(os.path.join(args.report, "**", "*kernel_trace.csv"), recursive=True)
+    assert files, "no kernel_trace.csv under " + args.report
+    rows = []
+    with open(files[0]) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    ops = plan_names(args.batch, args.size, args.size)
+    rows = [r for r in rows if r[2].startswith(("void rib::", "rib::"))]
+    n = len(ops)
+    total_steps = len(rows) // n
+    assert total_steps >= 1, (len(rows), n)
+    rows = rows[-n * min(args.steps, total_steps):]
+    steps = len(rows) // n
+    agg = [0.0] * n
+    for i, r in enumerate(rows):
+        agg[i % n] += (r[1] - r[0]) / 1e3 / steps          # us
+    span = sum((rows[(s + 1) * n - 1][1] - rows[s * n][0]) for s in range(steps)) / steps / 1e3
+    print("# %d steps, %d launches/step, sum of kernel time %.1f us, first-start to last-end %.1f us/step"
+          % (steps, n, sum(agg), span))
+    cls = {}
+    for o, t in zip(ops, agg):
+        cls.setdefault(o["class"], [0, 0.0]); cls[o["class"]][0] += 1; cls[o["class"]][1] += t
+    names = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
+    for k in sorted(cls):
+        print("# class %-8s launches %3d  %.1f us" % (names[k], cls[k][0], cls[k][1]))
+    print("%-52s %9s %8s  %-14s %s" % ("op", "us", "TFLOP/s", "grid", "tile"))
+    for o, t in zip(ops, agg):
+        tf = o["flops"] / (t * 1e-6) / 1e12 if t > 0 and o["flops"] else 0.0
+        print("%-52s %9.1f %8.1f  %-14s %s" % (o["name"], t, tf, o["grid"], o["tile"]))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump({"steps": steps, "sum_us": sum(agg), "span_us": span,
+                       "ops": [dict(o, us=t) for o, t in zip(ops, agg)]}, f, indent=0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--run", action="store_true")
+    ap.add_argument("--report", type=str, default=None)
+    ap.add_argument("--json", type=str, default=None)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    if a.run:
+        run(a)
+    else:
+        report(a)
