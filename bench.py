@@ -141,7 +141,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import generator_ref
         R = generator_ref.RefGenerator(spec, sd)
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))   # 16 threads is the fastest setting on the 256-CPU GPU box (tools/cpu_threads.py sweep: 8/16/32/64/128)
         lc, fc, pc = label.cpu(), fake.cpu(), prev.cpu()
         oimg, omask = R(lc, None, fc, pc)                       # warm-up + parity reference
         log("cpu oracle warm-up frame done (%d threads)" % torch.get_num_threads())

@@ -65,6 +65,8 @@ struct IgemmParams {
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
   float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
+  int ksplit;            // >= 1; > 1: K is split over blockIdx.z and partial sums go to `slab`
+  float* slab;           // [ksplit][B][Hout][Wout][CoutPad]
   // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
   const float* xm;       // tensor being normalised, [B][Hm][Wm][xmC]
   int xmC, xm_ups;       // xm_ups: xm is stored at half resolution (nearest x2 upsample on read)
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0), "SPADE needs gamma/beta fragment pairs");
   static_assert(!UPS || (STRIDE == 1 && KS == 3), "upsample gather only for 3x3 stride 1");
+  static_assert(256 % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   float* sA = smem;
   float* sB = smem + G::SA;
@@ -113,11 +116,16 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int n = blockIdx.z;
+  // blockIdx.z = n * ksplit + split: split-K slices share the tile and write partial slabs
+  const int n = blockIdx.z / p.ksplit;
+  const int split = blockIdx.z - n * p.ksplit;
   const int tile = blockIdx.x;
   const int ty0 = (tile / p.tilesX) * G::TH;
   const int tx0 = (tile % p.tilesX) * G::TW;
   const int n0 = blockIdx.y * G::BN;
+  const int nchunks = p.Cin / BK;
+  const int kc_begin = (split * nchunks / p.ksplit) * BK;
+  const int kc_end = ((split + 1) * nchunks / p.ksplit) * BK;
 
   // input-tile origin in stored-input coordinates
   int iy0, ix0;
@@ -141,7 +149,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
   const int wrow = G::TAPS * p.Cin;   // floats per filter row
 
-  // filter prefetch registers
+  // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
+  // filter slice / input chunk are in flight while the current one feeds the matrix cores ----
   float4 breg[G::NB4];
   auto loadB = [&](int kc, int tap) {
 #pragma unroll
@@ -164,30 +173,52 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
     }
   };
 
-  loadB(0, 0);
-  for (int kc = 0; kc < p.Cin; kc += BK) {
-    __syncthreads();   // every wave is done reading sA / sB of the previous chunk
-    // ---- stage the input halo tile for channels [kc, kc+BK) with the fused prologue ----
-    {
-      constexpr int total4 = G::IH * G::IW * (BK / 4);
-      for (int idx = tid; idx < total4; idx += 256) {
-        const int c4 = idx % (BK / 4);
-        const int pix = idx / (BK / 4);
-        const int ly = pix / G::IW, lx = pix % G::IW;
-        const int iy = iy0 + ly, ix = ix0 + lx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
-          v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.Win + ix) * p.xC + kc + c4 * 4);
-          if (p.pro_scale) {
-            const float4 s = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + c4 * 4);
-            const float4 t = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + c4 * 4);
-            v = make_float4(v.x * s.x + t.x, v.y * s.y + t.y, v.z * s.z + t.z, v.w * s.w + t.w);
-          }
-          if (p.pro_lrelu) v = lrelu4(v);
-        }
-        *reinterpret_cast<float4*>(sA + pix * G::CK + c4 * 4) = v;
-      }
+  constexpr int total4 = G::IH * G::IW * (BK / 4);
+  constexpr int NA4 = (total4 + 255) / 256;
+  const int ac4 = tid % (BK / 4);           // this thread's channel group, the same in every slot
+  float4 areg[NA4];
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto slot_inb = [&](int i, int& pix, int& iy, int& ix) -> bool {
+    const int idx = tid + i * 256;
+    pix = idx / (BK / 4);
+    const int ly = pix / G::IW, lx = pix % G::IW;
+    iy = iy0 + ly; ix = ix0 + lx;
+    return idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+  };
+  auto prefetchA = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+      int pix, iy, ix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (slot_inb(i, pix, iy, ix))
+        v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.Win + ix) * p.xC + kc + ac4 * 4);
+      areg[i] = v;
     }
+    if (p.pro_scale) {
+      psc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + ac4 * 4);
+      psh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * 4);
+    }
+  };
+  // fused prologue on the way into LDS: InstanceNorm affine + LeakyReLU; conv zero padding is
+  // applied AFTER the transform (the reference pads the activated tensor)
+  auto writeA = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA4; ++i) {
+      int pix, iy, ix;
+      const bool inb = slot_inb(i, pix, iy, ix);
+      float4 v = areg[i];
+      if (p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
+      if (p.pro_lrelu) v = lrelu4(v);
+      if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid + i * 256 < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
+    }
+  };
+
+  loadB(kc_begin, 0);
+  prefetchA(kc_begin);
+  for (int kc = kc_begin; kc < kc_end; kc += BK) {
+    __syncthreads();   // every wave is done reading sA / sB of the previous chunk
+    writeA();
 #pragma unroll 1
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int buf = tap & 1;
@@ -195,8 +226,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       {  // prefetch the next filter slice while this tap computes
         int ntap = tap + 1, nkc = kc;
         if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
-        if (nkc < p.Cin) loadB(nkc, ntap);
+        if (nkc < kc_end) loadB(nkc, ntap);
       }
+      // next input chunk: issued AFTER the filter load so that the in-order vmcnt wait at the
+      // next storeB does not have to cover it
+      if (tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
       __syncthreads();
       const int dy = tap / KS, dx = tap % KS;
       int aoff[MF];
@@ -230,7 +264,25 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 
   // ------------------------------------ epilogue ------------------------------------
   // accumulator element r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5)  (pixel), col = l&31 (channel)
-  if (!SPADE) {
+  if (!SPADE && p.ksplit > 1) {
+    // split-K: raw partial sums to slab [split][B][Hout][Wout][CoutPad]; k_splitk_epilogue finishes
+    float* slab = p.slab + ((size_t)split * gridDim.z / p.ksplit + n) * p.Hout * p.Wout * p.CoutPad;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int col = n0 + (wn * NF + nf) * 32 + li;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          const int ox = tx0 + row % FRW;
+          if (col < p.CoutPad && oy < p.Hout && ox < p.Wout)
+            slab[((size_t)oy * p.Wout + ox) * p.CoutPad + col] = acc[mf][nf][r];
+        }
+      }
+    }
+  } else if (!SPADE) {
     float s1[NF], s2[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
@@ -332,7 +384,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 //   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
 //   scale = rstd*gamma, shift = beta - mean*scale   (gamma=1, beta=0 when affine is absent)
 // Tiles are summed in a fixed order in fp64: deterministic and free of fp32 cancellation.
-// grid (Cs/32, B), block 256 = 32 channels x 8 tile slices.
+// grid (Cs/32, B), block 1024 = 32 channels x 32 tile slices.
 // ---------------------------------------------------------------------------------------------
 struct FinalizeParams {
   const float* part;   // [B][tiles][2][Cs]
@@ -346,15 +398,24 @@ struct FinalizeParams {
   float eps;
 };
 
-__global__ __launch_bounds__(256) void k_stats_finalize(const FinalizeParams p) {
-  __shared__ double red[2][8][32];
+__global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p) {
+  __shared__ double red[2][32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int n = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
   if (c < p.Cs) {
     const float* base = p.part + (size_t)n * p.tiles * 2 * p.Cs;
-    for (int t = sl; t < p.tiles; t += 8) {
+    int t = sl;
+    for (; t + 96 < p.tiles; t += 128) {   // 4 independent loads in flight per accumulator
+      const float x0 = base[(size_t)t * 2 * p.Cs + c], y0 = base[(size_t)t * 2 * p.Cs + p.Cs + c];
+      const float x1 = base[(size_t)(t + 32) * 2 * p.Cs + c], y1 = base[(size_t)(t + 32) * 2 * p.Cs + p.Cs + c];
+      const float x2 = base[(size_t)(t + 64) * 2 * p.Cs + c], y2 = base[(size_t)(t + 64) * 2 * p.Cs + p.Cs + c];
+      const float x3 = base[(size_t)(t + 96) * 2 * p.Cs + c], y3 = base[(size_t)(t + 96) * 2 * p.Cs + p.Cs + c];
+      a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+      a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+    }
+    for (; t < p.tiles; t += 32) {
       a1 += (double)base[(size_t)t * 2 * p.Cs + c];
       a2 += (double)base[(size_t)t * 2 * p.Cs + p.Cs + c];
     }
@@ -365,7 +426,7 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const FinalizeParams p) 
   if (sl == 0 && c < p.C) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    for (int k = 0; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     const double mean = s1 * (double)p.inv_count;
     double var = s2 * (double)p.inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -375,6 +436,76 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const FinalizeParams p) 
     const float sc = rstd * g;
     p.scale[(size_t)n * p.ld + p.off + c] = sc;
     p.shift[(size_t)n * p.ld + p.off + c] = b - (float)mean * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_splitk_epilogue: finishes a split-K convolution: sums the partial slabs in a fixed order, then
+// the same epilogue as k_igemm (bias, residual, activation, store, per-block statistics partials).
+// grid (blocks, B); thread = (pixel slot, 4-channel group); block covers slots*4 pixels.
+// ---------------------------------------------------------------------------------------------
+struct SplitEpiParams {
+  const float* slab; int ksplit; int B;
+  const float* bias; int CoutPad;
+  float* y; int yC, yoff, Cout;
+  int act;
+  const float* res; int resC, res_ups;
+  float* stat_part; int blocks;
+  int Hout, Wout;
+};
+
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p) {
+  __shared__ __attribute__((aligned(16))) float red[2][256][4];
+  const int c4n = p.CoutPad / 4;
+  const int slots = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
+  const int n = blockIdx.y;
+  const int npix = p.Hout * p.Wout;
+  const int ppb = slots * 4;
+  const size_t sstride = (size_t)p.B * npix * p.CoutPad;
+  const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int k = 0; k < 4; ++k) {
+    const int pix = blockIdx.x * ppb + k * slots + slot;
+    if (pix < npix) {
+      const float* src = p.slab + ((size_t)n * npix + pix) * p.CoutPad + c4 * 4;
+      float4 a = *reinterpret_cast<const float4*>(src);
+      for (int s = 1; s < p.ksplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(src + s * sstride);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+      float v[4] = {a.x, a.y, a.z, a.w};
+      const int oy = pix / p.Wout, ox = pix % p.Wout;
+      const size_t opix = (size_t)n * npix + pix;
+      const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : opix;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = c4 * 4 + e;
+        if (col < p.Cout) {
+          float t = v[e];
+          if (p.res) t += p.res[rpix * p.resC + col];
+          t = apply_act(t, p.act);
+          p.y[opix * p.yC + p.yoff + col] = t;
+          v[e] = t;
+        } else v[e] = 0.f;
+      }
+      s1.x += v[0]; s1.y += v[1]; s1.z += v[2]; s1.w += v[3];
+      s2.x += v[0] * v[0]; s2.y += v[1] * v[1]; s2.z += v[2] * v[2]; s2.w += v[3] * v[3];
+    }
+  }
+  if (p.stat_part) {
+    *reinterpret_cast<float4*>(&red[0][threadIdx.x][0]) = s1;
+    *reinterpret_cast<float4*>(&red[1][threadIdx.x][0]) = s2;
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
+      const int g = c / 4, e = c % 4;
+      float a1 = 0.f, a2 = 0.f;
+      for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
+      float* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
+      dst[c] = a1;
+      dst[p.CoutPad + c] = a2;
+    }
   }
 }
 

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -147,6 +148,10 @@ struct Variant {
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
   int BN() const { return 32 * NF * WN; }
+  int lds_bytes() const {
+    const int ih = UPS ? TH() / 2 + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() / 2 + 2 : (TW() - 1) * STRIDE + KS;
+    return (ih * iw * (BK + 4) + 2 * BN() * (BK + 4)) * 4;
+  }
 };
 #define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP>}
@@ -156,7 +161,8 @@ const Variant kVariants[] = {
     RIB_V(16, 4, 1, 1, 1, 8, 1, 3, false, false),  RIB_V(16, 4, 1, 1, 2, 8, 1, 3, false, false),
     RIB_V(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 3, false, false),
     RIB_V(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 3, false, false),
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false),
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false), RIB_V(8, 2, 2, 1, 1, 32, 1, 3, false, false),
+    RIB_V(16, 4, 1, 2, 2, 32, 1, 3, false, false),
     // 3x3 stride 2
     RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
     // 3x3 on a nearest-x2-upsampled input
@@ -170,24 +176,39 @@ const Variant kVariants[] = {
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-// choose a variant: exact (BK,STRIDE,KS,UPS,SPADE); geometry by column count and grid fill
-const Variant* pick_variant(int BK, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout) {
-  const Variant* best = nullptr;
-  double best_score = -1e30;
+// Choose (variant, split-K factor) with a small analytic cost model, in shader cycles:
+//   per wave and tap   (BK/8)*MF*NF*4 MFMAs of 64 cycles + a fixed barrier/LDS overhead
+//   latency bound      rounds of resident workgroups x the dependent chain of one workgroup
+//   matrix-core bound  each CU runs the MFMAs of its workgroups serially on its 4 SIMDs
+// A split-K launch pays a second (slab-summing) kernel.
+struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
+
+Choice choose_variant(int BK, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+                      int Cin, bool allow_split) {
+  Choice best;
+  best.cycles = 1e300;
+  const int nchunks = Cin / BK;
+  static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
     if (v.BK != BK || v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade) continue;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
     const long ntiles = (ncols + v.BN() - 1) / v.BN();
-    const long wgs = tiles * ntiles * B;
-    // useful fraction of the MFMA work the grid issues (tile overhang in pixels and columns)
-    const double eff_n = (double)ncols / (double)(ntiles * v.BN());
-    const double eff_m = (double)Hout * Wout / (double)(tiles * v.TH() * v.TW());
-    const double fill = std::min(1.0, (double)wgs / 512.0);   // 2 workgroups per CU fills the chip
-    // bigger tiles reuse operands better: mild preference
-    const double reuse = 1.0 + 0.05 * std::log2((double)v.TH() * v.TW() * v.BN() / 1024.0);
-    const double score = eff_n * eff_m * fill * reuse;
-    if (score > best_score) { best_score = score; best = &v; }
+    const int occ = std::max(1, std::min(5, 160 * 1024 / v.lds_bytes()));
+    for (int S : kSplits) {
+      if (S > nchunks || (S > 1 && !allow_split)) break;
+      const long wgs = tiles * ntiles * B * S;
+      const int chunks = (nchunks + S - 1) / S;
+      const int taps = ks * ks;
+      const double mfma_tap = (BK / 8) * v.MF * v.NF * 4 * 64.0;
+      const double wg_chain = chunks * (taps * (mfma_tap + 350.0) + 500.0) + 3000.0;
+      const double mfma_wg = (double)chunks * taps * mfma_tap;
+      const double t_lat = std::ceil((double)wgs / (256.0 * occ)) * wg_chain;
+      const double t_mfma = std::ceil((double)wgs / 256.0) * mfma_wg;
+      double t = std::max(t_lat, t_mfma);
+      if (S > 1) t += 6000.0 + (double)(S + 1) * B * Hout * Wout * pad32(ncols) * 4.0 / 1667.0;
+      if (t < best.cycles) { best.cycles = t; best.v = &v; best.ksplit = S; }
+    }
   }
   return best;
 }
@@ -195,7 +216,7 @@ const Variant* pick_variant(int BK, int stride, int ks, bool ups, bool spade, in
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
-enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD };
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI };
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
@@ -213,7 +234,9 @@ struct Op {
   // igemm
   const Variant* var = nullptr;
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
-  PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1;
+  PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab;
+  // split-K epilogue
+  SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
   dim3 grid;
   double flops = 0;
   // finalize
@@ -408,8 +431,13 @@ struct Builder {
     const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
     const int BK = pick_bk(c.cinp);
-    const Variant* v = pick_variant(BK, c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout);
+    // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
+    // and no NCHW side copy
+    const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
+    const Choice ch = choose_variant(BK, c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split);
+    const Variant* v = ch.v;
     if (!v) { error = fmt("%s: no kernel variant for BK=%d stride=%d ks=%d ups=%d", opname.c_str(), BK, c.stride, c.ks, (int)a.ups); return false; }
+    const int S = ch.ksplit;
     Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = opname; op.var = v;
     IgemmParams& p = op.ip;
     memset(&p, 0, sizeof p);
@@ -418,7 +446,7 @@ struct Builder {
     p.CoutPad = c.coutp;
     p.Hout = Hout; p.Wout = Wout;
     p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
-    p.act = a.act;
+    p.act = a.act; p.ksplit = S;
     op.x = WS(a.in.off);
     if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
     op.w = WT(c.w_off); op.bias = WT(c.b_off);
@@ -431,13 +459,33 @@ struct Builder {
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
-    const int tiles = p.tilesX * p.tilesY;
+    int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
-    if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
-    op.grid = dim3(tiles, (c.coutp + v->BN() - 1) / v->BN(), B);
+    op.grid = dim3(tiles, (c.coutp + v->BN() - 1) / v->BN(), B * S);
     op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B;
     P->flops[RIB_KC_IGEMM] += op.flops;
-    P->ops.push_back(op);
+    if (S == 1) {
+      if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
+      P->ops.push_back(op);
+    } else {
+      // split-K: the conv writes raw partial slabs; a second kernel sums them and runs the epilogue
+      const size_t slab_off = alloc((size_t)S * B * Hout * Wout * c.coutp * sizeof(float));
+      op.slab = WS(slab_off);
+      Op e; e.kind = OP_SPLITEPI; e.kclass = RIB_KC_ELTWISE; e.name = opname + ".splitk_sum";
+      memset(&e.sp, 0, sizeof e.sp);
+      e.sp.ksplit = S; e.sp.B = B; e.sp.CoutPad = c.coutp; e.sp.yC = p.yC; e.sp.yoff = p.yoff; e.sp.Cout = p.Cout;
+      e.sp.act = p.act; e.sp.resC = p.resC; e.sp.res_ups = p.res_ups; e.sp.Hout = Hout; e.sp.Wout = Wout;
+      const int slots = 256 / (c.coutp / 4), ppb = slots * 4;
+      const int blocks = (Hout * Wout + ppb - 1) / ppb;
+      e.sp.blocks = blocks;
+      e.s_slab = WS(slab_off); e.s_bias = op.bias; e.s_y = op.y; e.s_res = op.res;
+      if (a.want_stats) { part_off = alloc((size_t)B * blocks * 2 * c.coutp * sizeof(float)); e.s_stat = WS(part_off); }
+      e.grid = dim3(blocks, B, 1);
+      tiles = blocks;   // the statistics partials now come from the epilogue kernel's blocks
+      op.y = PRef(); op.res = PRef();
+      P->ops.push_back(op);
+      P->ops.push_back(e);
+    }
     if (a.want_stats) {
       Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
       memset(&f.fp, 0, sizeof f.fp);
@@ -461,7 +509,7 @@ struct Builder {
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
     if (cond.Cp != pad8(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
     if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
-    const Variant* v = pick_variant(32, 1, 1, false, true, sg.npad, B, Hout, Wout);
+    const Variant* v = choose_variant(32, 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
     if (!v) { error = "no SPADE variant"; return false; }
     *ys0 = act(sg.C, Hout, Wout);
     if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
@@ -471,6 +519,7 @@ struct Builder {
     p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
     p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout;
     p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
+    p.ksplit = 1;
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
     op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off);
@@ -744,7 +793,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
         p.x = R.get<const float>(op.x); p.pro_scale = R.get<const float>(op.pro_scale); p.pro_shift = R.get<const float>(op.pro_shift);
         p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
         p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
-        p.stat_part = R.get<float>(op.stat);
+        p.stat_part = R.get<float>(op.stat); p.slab = R.get<float>(op.slab);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
         hipLaunchKernelGGL(op.var->fn, op.grid, dim3(256), 0, st, p);
@@ -753,7 +802,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
         FinalizeParams p = op.fp;
         p.part = R.get<const float>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
         p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
-        hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(1024), 0, st, p);
+      } break;
+      case OP_SPLITEPI: {
+        SplitEpiParams p = op.sp;
+        p.slab = R.get<const float>(op.s_slab); p.bias = R.get<const float>(op.s_bias); p.y = R.get<float>(op.s_y);
+        p.res = R.get<const float>(op.s_res); p.stat_part = R.get<float>(op.s_stat);
+        hipLaunchKernelGGL(k_splitk_epilogue, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_POOL: {
         PoolParams p = op.pp;
@@ -1128,8 +1183,8 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
   const Op& op = P->ops[idx];
   if (op.kind == OP_IGEMM)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.flops);
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;
