@@ -136,6 +136,16 @@ int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms
 int rib_forward_flops(rib_handle* h, int B, int H, int W, double flops[RIB_KC_COUNT]);
 int rib_num_launches(rib_handle* h, int B, int H, int W);
 
+/* ---- tuning hooks (tools/autotune.py): the launch plan picks, per convolution, one of a small set
+ * of tile geometries and a split-K factor from an analytic cost model; a measured choice can be
+ * pinned per (B,H,W, op name).  geom = {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE}. ---- */
+int rib_num_variants(void);
+int rib_variant_info(int idx, int geom[10]);
+int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit);
+int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label,
+                const float* img_fake, const float* img_prev, float* img, float* mask, void* workspace,
+                size_t workspace_bytes, int iters, void* hip_stream, double* usec);
+
 /* ---- host-only debugging (CPU tests): rib_create(cfg, device = -1, ..) builds a handle that owns
  * no device memory; it supports the tensor inventory, rib_set_tensor / rib_finalize_weights (the
  * folded blob stays on the host), plans (workspace size, launch list, FLOPs) and these readers,

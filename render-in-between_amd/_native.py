@@ -59,6 +59,11 @@ SIGNATURES = {
     "rib_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "rib_forward_flops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rib_num_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rib_num_variants": (C.c_int, []),
+    "rib_variant_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "rib_set_choice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]),
+    "rib_time_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p] + [C.c_void_p] * 6
+                    + [C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
     "rib_debug_conv_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "rib_debug_spade_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "rib_debug_launch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),

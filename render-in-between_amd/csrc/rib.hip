@@ -157,22 +157,32 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP>}
 
 const Variant kVariants[] = {
-    // 3x3 stride 1
+    // 3x3 stride 1, tile 8x16 (4 waves along M), BN 32 / 64
     RIB_V(16, 4, 1, 1, 1, 8, 1, 3, false, false),  RIB_V(16, 4, 1, 1, 2, 8, 1, 3, false, false),
     RIB_V(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 3, false, false),
     RIB_V(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 3, false, false),
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false), RIB_V(8, 2, 2, 1, 1, 32, 1, 3, false, false),
-    RIB_V(16, 4, 1, 2, 2, 32, 1, 3, false, false),
+    // 3x3 stride 1, small tiles for the deep, small-spatial layers
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 1, 32, 1, 3, false, false),
+    RIB_V(8, 2, 2, 1, 1, 16, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 1, 3, false, false),
+    // 3x3 stride 1, 16x16 tile (two fragments per wave)
+    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 16, 1, 3, false, false),
     // 3x3 stride 2
     RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
+    RIB_V(8, 2, 2, 1, 1, 16, 2, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 2, 3, false, false),
+    RIB_V(16, 4, 1, 1, 1, 16, 2, 3, false, false),
     // 3x3 on a nearest-x2-upsampled input
     RIB_V(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 32, 1, 3, true, false),
+    RIB_V(16, 4, 1, 1, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 16, 1, 3, true, false),
+    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, true, false),
     // 1x1
     RIB_V(16, 4, 1, 1, 1, 16, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 1, false, false),
     RIB_V(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, false),
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 1, false, false),
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 1, false, false),  RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, false),
+    RIB_V(8, 2, 2, 1, 1, 64, 1, 1, false, false),
     // SPADE: 1x1 gamma/beta GEMM on the condition map + modulate epilogue
     RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_V(8, 1, 4, 1, 2, 32, 1, 1, false, true),
+    RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_V(8, 2, 2, 1, 2, 64, 1, 1, false, true),
+    RIB_V(16, 4, 1, 1, 4, 32, 1, 1, false, true),
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -183,29 +193,33 @@ const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // A split-K launch pays a second (slab-summing) kernel.
 struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
 
-Choice choose_variant(int BK, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                       int Cin, bool allow_split) {
   Choice best;
   best.cycles = 1e300;
-  const int nchunks = Cin / BK;
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
-    if (v.BK != BK || v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade) continue;
+    if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0) continue;
+    const int BK = v.BK;
+    const int nchunks = Cin / BK;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
     const long ntiles = (ncols + v.BN() - 1) / v.BN();
-    const int occ = std::max(1, std::min(5, 160 * 1024 / v.lds_bytes()));
+    const int occ = std::max(1, std::min(v.MF * v.NF >= 4 ? 4 : 6, 160 * 1024 / v.lds_bytes()));
     for (int S : kSplits) {
       if (S > nchunks || (S > 1 && !allow_split)) break;
       const long wgs = tiles * ntiles * B * S;
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ks * ks;
       const double mfma_tap = (BK / 8) * v.MF * v.NF * 4 * 64.0;
-      const double wg_chain = chunks * (taps * (mfma_tap + 350.0) + 500.0) + 3000.0;
+      // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
+      // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
+      // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
+      const double ovh_wg = chunks * (taps * 350.0 + 600.0) + 7000.0;
       const double mfma_wg = (double)chunks * taps * mfma_tap;
-      const double t_lat = std::ceil((double)wgs / (256.0 * occ)) * wg_chain;
-      const double t_mfma = std::ceil((double)wgs / 256.0) * mfma_wg;
-      double t = std::max(t_lat, t_mfma);
+      const double t_lat = std::ceil((double)wgs / (256.0 * occ)) * (mfma_wg + ovh_wg);
+      const double t_cu = std::ceil((double)wgs / 256.0) * (mfma_wg + ovh_wg / occ);
+      double t = std::max(t_lat, t_cu);
       if (S > 1) t += 6000.0 + (double)(S + 1) * B * Hout * Wout * pad32(ncols) * 4.0 / 1667.0;
       if (t < best.cycles) { best.cycles = t; best.v = &v; best.ksplit = S; }
     }
@@ -285,6 +299,8 @@ struct rib_handle {
   size_t blob_floats = 0;
   bool weights_ready = false;
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
+  // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
+  std::map<std::string, std::pair<int, int>> choices;
   // profiling
   bool profiling = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -430,13 +446,23 @@ struct Builder {
     const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
     const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
-    const int BK = pick_bk(c.cinp);
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
-    const Choice ch = choose_variant(BK, c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split);
+    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split);
+    {
+      auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, opname.c_str()));
+      if (it != h->choices.end()) {
+        const Variant& tv = kVariants[it->second.first];
+        const int ts = it->second.second;
+        const bool ok = tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+                        ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
+        if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
+        ch.v = &tv; ch.ksplit = ts;
+      }
+    }
     const Variant* v = ch.v;
-    if (!v) { error = fmt("%s: no kernel variant for BK=%d stride=%d ks=%d ups=%d", opname.c_str(), BK, c.stride, c.ks, (int)a.ups); return false; }
+    if (!v) { error = fmt("%s: no kernel variant for Cin=%d stride=%d ks=%d ups=%d", opname.c_str(), c.cinp, c.stride, c.ks, (int)a.ups); return false; }
     const int S = ch.ksplit;
     Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = opname; op.var = v;
     IgemmParams& p = op.ip;
@@ -509,7 +535,15 @@ struct Builder {
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
     if (cond.Cp != pad8(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
     if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
-    const Variant* v = choose_variant(32, 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    const Variant* v = choose_variant(1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    {
+      auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
+      if (it != h->choices.end()) {
+        const Variant& tv = kVariants[it->second.first];
+        if (!(tv.SPADE && tv.KS == 1 && cond.Cp % tv.BK == 0 && it->second.second == 1)) { error = key + ": tuned SPADE choice does not fit"; return false; }
+        v = &tv;
+      }
+    }
     if (!v) { error = "no SPADE variant"; return false; }
     *ys0 = act(sg.C, Hout, Wout);
     if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
@@ -1188,6 +1222,64 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;
+}
+
+// ---- tuning hooks: enumerate kernel variants, pin a (variant, split-K) choice for one op of one
+// shape, and time a single op of the plan in isolation ----
+int rib_num_variants(void) { return kNumVariants; }
+
+int rib_variant_info(int idx, int geom[10]) {
+  if (idx < 0 || idx >= kNumVariants || !geom) return RIB_ERR_INVALID;
+  const Variant& v = kVariants[idx];
+  const int g[10] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0};
+  for (int i = 0; i < 10; ++i) geom[i] = g[i];
+  return RIB_OK;
+}
+
+int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit) {
+  if (!h || !op_name) return RIB_ERR_INVALID;
+  const std::string key = fmt("%d,%d,%d|%s", B, H, W, op_name);
+  if (variant_idx < 0) h->choices.erase(key);
+  else {
+    if (variant_idx >= kNumVariants || ksplit < 1) return fail(h, RIB_ERR_INVALID, "rib_set_choice: bad variant / ksplit");
+    h->choices[key] = {variant_idx, ksplit};
+  }
+  h->plans.erase(((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W);   // rebuilt on next use
+  return RIB_OK;
+}
+
+int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label, const float* img_fake,
+                const float* img_prev, float* img, float* mask, void* workspace, size_t workspace_bytes, int iters,
+                void* hip_stream, double* usec) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!op_name || !workspace || !usec || iters < 1) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P) return RIB_ERR_INVALID;
+  if (workspace_bytes < P->ws_bytes) return fail(h, RIB_ERR_WORKSPACE, "rib_time_op: workspace too small");
+  // a sub-plan holding the op and, for split-K, its slab-summing epilogue
+  Plan sub; sub.B = B; sub.H = H; sub.W = W;
+  const std::string nm = op_name;
+  for (const Op& op : P->ops)
+    if (op.name == nm || op.name == nm + ".splitk_sum") sub.ops.push_back(op);
+  if (sub.ops.empty()) return fail(h, RIB_ERR_INVALID, fmt("rib_time_op: no op named '%s'", op_name));
+  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
+  R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const bool was = h->profiling; h->profiling = false;
+  rc = run_plan(h, &sub, R, st);   // warm-up
+  hipEvent_t e0, e1;
+  HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+  HIP_TRY(h, hipEventRecord(e0, st));
+  for (int i = 0; i < iters && rc == RIB_OK; ++i) rc = run_plan(h, &sub, R, st);
+  HIP_TRY(h, hipEventRecord(e1, st));
+  HIP_TRY(h, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  h->profiling = was;
+  *usec = (double)ms * 1e3 / iters;
+  return rc;
 }
 
 int rib_profile_begin(rib_handle* h) {

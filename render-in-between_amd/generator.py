@@ -28,8 +28,10 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Generator:
-    def __init__(self, gen_cfg, device=None):
+    def __init__(self, gen_cfg, device=None, use_tuning=True):
         self.spec = GenSpec.from_cfg(gen_cfg)
+        self._tuning = None
+        self._use_tuning = use_tuning
         self.gen_cfg = gen_cfg
         if not torch.cuda.is_available():
             raise RuntimeError("render_in_between_amd.Generator needs a ROCm GPU (MI355X); "
@@ -143,7 +145,17 @@ class Generator:
         key = (B, H, W)
         ws = self._ws.get(key)
         if ws is None:
+            if self._use_tuning:
+                from . import tuning
+                if self._tuning is None:
+                    self._tuning = tuning.load()
+                tuning.apply(self._lib, self._h, self._tuning, B, H, W)
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
+            if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (B, H, W)):
+                # a stale tuning entry must never break the path: drop it and use the cost model
+                for op in self._tuning["%d,%d,%d" % (B, H, W)]:
+                    self._lib.rib_set_choice(self._h, B, H, W, op.encode(), -1, 1)
+                n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0:
                 _native.check(self._h, -1)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)

@@ -1,0 +1,43 @@
+"""Measured kernel choices (tools/autotune.py) for gfx950: per (B,H,W) and per
+launch, the tile geometry {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE} and split-K
+factor that ran fastest on an MI355X.  Shapes without an entry fall back to the
+analytic cost model in csrc/rib.hip (choose_variant)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+
+
+def load(path=TUNING_PATH):
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+def save(table, path=TUNING_PATH):
+    with open(path, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+
+
+def apply(lib, handle, table, B, H, W):
+    """Pin the tuned choices of shape (B,H,W) on a handle; returns how many were applied."""
+    entry = table.get("%d,%d,%d" % (B, H, W))
+    if not entry:
+        return 0
+    g10 = (C.c_int * 10)()
+    geoms = {}
+    for i in range(lib.rib_num_variants()):
+        lib.rib_variant_info(i, g10)
+        geoms[tuple(g10)] = i
+    n = 0
+    for op, choice in entry.items():
+        idx = geoms.get(tuple(choice[:10]))
+        if idx is None:
+            continue                      # variant table changed since tuning: model choice
+        if lib.rib_set_choice(handle, B, H, W, op.encode(), idx, int(choice[10])) == 0:
+            n += 1
+    return n

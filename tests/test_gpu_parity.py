@@ -119,7 +119,9 @@ def test_known_answer_properties_on_gpu():
     b = G(label, torch.randn_like(label), fake, prev)            # label_prev is dead (F3)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])   # and the path is deterministic
     c = G(label[1:], None, fake[1:], prev[1:])                   # batch independence (F9)
-    assert torch.equal(a[0][1:], c[0]) and torch.equal(a[1][1:], c[1])
+    # a different batch size may pick different tiles / split-K factors, i.e. another fp32
+    # summation order: equal to rounding, not bit for bit
+    assert float((a[0][1:] - c[0]).abs().max()) <= 5e-5 and float((a[1][1:] - c[1]).abs().max()) <= 5e-5
     assert float(a[0].abs().max()) < 1.0 and 0.0 < float(a[1].min()) and float(a[1].max()) < 1.0
 
 
