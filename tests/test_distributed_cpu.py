@@ -58,5 +58,5 @@ def test_broadcast_and_sharding_world2():
 
 def test_shard_units_edge_cases():
     assert ribdist.shard_units(0, 0, 4) == []
-    assert ribdist.shard_units(3, 3, 8) == [3] and ribdist.shard_units(3, 5, 8) == []
+    assert ribdist.shard_units(3, 2, 8) == [2] and ribdist.shard_units(3, 3, 8) == [] and ribdist.shard_units(3, 5, 8) == []
     assert sum(len(ribdist.shard_units(32, r, 8)) for r in range(8)) == 32
