@@ -9,8 +9,13 @@
  *
  * Ownership: the caller owns every tensor and the workspace; a handle owns only the weight blob
  * and its launch plans.  A handle is bound to one device, is single-stream and not re-entrant
- * (one handle per GPU / process).  All kernels are enqueued on the caller's stream; no entry point
- * synchronises the device except rib_finalize_weights(), rib_read_tap() and rib_profile_collect().
+ * (one handle per GPU / process).  Work is ordered on the caller's stream: a forward may fork its two
+ * independent branches (condition encoder, label branch of the mask network) onto handle-owned
+ * side streams, but they start after everything already queued on the caller's stream and are
+ * joined back into it before the outputs are written (opt-in with RIB_STREAMS=1: measured slower
+ * than one stream at batch 1, so off by default).
+ * No entry point synchronises the device except rib_finalize_weights(), rib_read_tap() and
+ * rib_profile_collect().
  *
  * Tensors at the boundary are dense fp32 NCHW on the handle's device, exactly what the reference
  * generator takes and returns (PGNR/models/evaluator.py:250-255).

@@ -65,8 +65,8 @@ struct IgemmParams {
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
   float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
-  int ksplit;            // >= 1; > 1: K is split over blockIdx.z and partial sums go to `slab`
-  float* slab;           // [ksplit][B][Hout][Wout][CoutPad]
+  int ksplit;            // >= 1: K is split over blockIdx.z
+  float* slab;           // when set: raw partial sums go to [ksplit][B][Hout][Wout][CoutPad] instead of y
   // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
   const float* xm;       // tensor being normalised, [B][Hm][Wm][xmC]
   int xmC, xm_ups;       // xm_ups: xm is stored at half resolution (nearest x2 upsample on read)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 
   // ------------------------------------ epilogue ------------------------------------
   // accumulator element r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5)  (pixel), col = l&31 (channel)
-  if (!SPADE && p.ksplit > 1) {
+  if (!SPADE && p.slab != nullptr) {
     // split-K: raw partial sums to slab [split][B][Hout][Wout][CoutPad]; k_splitk_epilogue finishes
     float* slab = p.slab + ((size_t)split * gridDim.z / p.ksplit + n) * p.Hout * p.Wout * p.CoutPad;
 #pragma unroll
@@ -506,6 +506,64 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       dst[c] = a1;
       dst[p.CoutPad + c] = a2;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_spade_modulate: second half of an UNFUSED SPADE (used where the map is small and the fused
+// kernel cannot fill the chip): the gamma/beta 1x1 GEMM ran as a (split-K) convolution into
+// slab [S][B][HW][npad] with the fused kernel's column layout ([gamma(32) | beta(32)] per 32
+// virtual channels, virtual channel v = set*C + c); this kernel sums the slices and applies
+//   out_set = act_set( (x*scale + shift) * (1 + gamma) + beta )
+// thread = (pixel, 4 virtual channels); grid (blocks, B).
+// ---------------------------------------------------------------------------------------------
+struct ModulateParams {
+  const float* slab; int ksplit, B, npad;
+  const float* bias;
+  const float* xm; int xmC, xm_ups;
+  const float* m_scale; const float* m_shift; int m_ld;
+  int C, nsets;
+  float* ys0; float* ys1; int act0, act1;
+  int Hout, Wout;
+};
+
+__global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) {
+  const int v4n = p.nsets * p.C / 4;
+  const int n = blockIdx.y;
+  const int npix = p.Hout * p.Wout;
+  const size_t total = (size_t)npix * v4n;
+  const size_t sstride = (size_t)p.B * npix * p.npad;
+  const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int v = (int)(i % v4n) * 4;
+    const int pix = (int)(i / v4n);
+    const int colg = (v / 32) * 64 + (v % 32);
+    const float* src = p.slab + ((size_t)n * npix + pix) * p.npad + colg;
+    float4 g = *reinterpret_cast<const float4*>(src);
+    float4 b = *reinterpret_cast<const float4*>(src + 32);
+    for (int s = 1; s < p.ksplit; ++s) {
+      const float4 g2 = *reinterpret_cast<const float4*>(src + s * sstride);
+      const float4 b2 = *reinterpret_cast<const float4*>(src + s * sstride + 32);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+    }
+    const float4 bg = *reinterpret_cast<const float4*>(p.bias + colg);
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + colg + 32);
+    const int set = v >= p.C ? 1 : 0;
+    const int c = v - set * p.C;
+    const int oy = pix / p.Wout, ox = pix % p.Wout;
+    const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+    const float4 x = *reinterpret_cast<const float4*>(p.xm + (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
+    const float4 sc = *reinterpret_cast<const float4*>(p.m_scale + (size_t)n * p.m_ld + c);
+    const float4 sh = *reinterpret_cast<const float4*>(p.m_shift + (size_t)n * p.m_ld + c);
+    const int act = set ? p.act1 : p.act0;
+    float4 o;
+    o.x = apply_act((x.x * sc.x + sh.x) * (1.f + (g.x + bg.x)) + (b.x + bb.x), act);
+    o.y = apply_act((x.y * sc.y + sh.y) * (1.f + (g.y + bg.y)) + (b.y + bb.y), act);
+    o.z = apply_act((x.z * sc.z + sh.z) * (1.f + (g.z + bg.z)) + (b.z + bb.z), act);
+    o.w = apply_act((x.w * sc.w + sh.w) * (1.f + (g.w + bg.w)) + (b.w + bb.w), act);
+    float* yout = set ? p.ys1 : p.ys0;
+    *reinterpret_cast<float4*>(yout + ((size_t)n * npix + pix) * p.C + c) = o;
   }
 }
 

@@ -230,7 +230,7 @@ Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
-enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI };
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE };
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
@@ -241,16 +241,27 @@ struct PRef {
   size_t off = 0;   // bytes for WS, floats for WEIGHT, slot id for USER
 };
 
+// Streams of a plan: the SPADE condition encoder (ref_embedding) and the label branch of the mask
+// network do not depend on the main generator chain, so they run on side streams forked from the
+// caller's stream and joined by events where their results are consumed.  Several of the deep
+// layers fill well under half of the 256 CUs at batch 1: co-running branches fill the rest.
+enum { ST_MAIN = 0, ST_EMBED = 1, ST_LABEL = 2, ST_COUNT = 3 };
+
 struct Op {
   OpKind kind;
   int kclass;
   std::string name;
+  int stream = ST_MAIN;
+  std::vector<int> wait_ev;   // plan events this op waits for (on its stream) before it launches
+  int record_ev = -1;         // plan event recorded on its stream after it launches
   // igemm
   const Variant* var = nullptr;
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab;
   // split-K epilogue
   SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
+  // unfused SPADE modulate
+  ModulateParams mp; PRef m_slab, m_bias, m_xm, m_sc, m_sh, m_ys0, m_ys1;
   dim3 grid;
   double flops = 0;
   // finalize
@@ -276,6 +287,7 @@ struct Norm {      // (scale, shift) arrays [B][ld]
 
 struct Plan {
   int B, H, W;
+  int num_events = 0;
   size_t ws_bytes = 0;
   std::vector<Op> ops;
   std::vector<Tap> taps;
@@ -301,6 +313,10 @@ struct rib_handle {
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
+  // side streams (forked from / joined to the caller's stream with events) and the event pool
+  hipStream_t side[ST_COUNT] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> events;
+  bool use_streams = true;
   // profiling
   bool profiling = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -405,6 +421,19 @@ struct Builder {
   int B;
   size_t ws = 0;
   std::string error;
+  int cur_stream = ST_MAIN;
+  std::vector<int> pending_waits;   // attached to the next op pushed
+
+  int new_event() { return P->num_events++; }
+  void push(Op op) {
+    op.stream = cur_stream;
+    op.wait_ev.insert(op.wait_ev.end(), pending_waits.begin(), pending_waits.end());
+    pending_waits.clear();
+    P->ops.push_back(op);
+  }
+  // record an event after the last op pushed
+  int record_after_last() { const int e = new_event(); P->ops.back().record_ev = e; return e; }
+  void wait_before_next(int ev) { if (ev >= 0) pending_waits.push_back(ev); }
 
   size_t alloc(size_t bytes) { size_t o = ws; ws += align256(bytes); return o; }
   Act act(int C, int H, int W) {
@@ -492,7 +521,7 @@ struct Builder {
     P->flops[RIB_KC_IGEMM] += op.flops;
     if (S == 1) {
       if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
-      P->ops.push_back(op);
+      push(op);
     } else {
       // split-K: the conv writes raw partial slabs; a second kernel sums them and runs the epilogue
       const size_t slab_off = alloc((size_t)S * B * Hout * Wout * c.coutp * sizeof(float));
@@ -509,8 +538,8 @@ struct Builder {
       e.grid = dim3(blocks, B, 1);
       tiles = blocks;   // the statistics partials now come from the epilogue kernel's blocks
       op.y = PRef(); op.res = PRef();
-      P->ops.push_back(op);
-      P->ops.push_back(e);
+      push(op);
+      push(e);
     }
     if (a.want_stats) {
       Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
@@ -522,7 +551,7 @@ struct Builder {
       if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
       f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
       f.grid = dim3(c.coutp / 32, B, 1);
-      P->ops.push_back(f);
+      push(f);
     }
     return true;
   }
@@ -535,16 +564,55 @@ struct Builder {
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
     if (cond.Cp != pad8(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
     if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
+    // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
+    // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
+    // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
     const Variant* v = choose_variant(1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    Choice uf;   // unfused candidate
+    const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
+    if (small_map) uf = choose_variant(1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
+    bool unfused = small_map && uf.v != nullptr;
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
-        if (!(tv.SPADE && tv.KS == 1 && cond.Cp % tv.BK == 0 && it->second.second == 1)) { error = key + ": tuned SPADE choice does not fit"; return false; }
-        v = &tv;
+        const int ts = it->second.second;
+        if (tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
+          error = key + ": tuned SPADE choice does not fit"; return false;
+        }
+        if (tv.SPADE) { v = &tv; unfused = false; }
+        else { uf.v = &tv; uf.ksplit = ts; unfused = true; }
       }
     }
-    if (!v) { error = "no SPADE variant"; return false; }
+    if (!unfused && !v) { error = "no SPADE variant"; return false; }
+    if (unfused) {
+      *ys0 = act(sg.C, Hout, Wout);
+      if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
+      const Variant* cv = uf.v; const int S = uf.ksplit;
+      const size_t slab_off = alloc((size_t)S * B * Hout * Wout * sg.npad * sizeof(float));
+      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = cv;
+      IgemmParams& p = op.ip;
+      memset(&p, 0, sizeof p);
+      p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
+      p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
+      p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH();
+      op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
+      op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
+      op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
+      P->flops[RIB_KC_SPADE] += op.flops;
+      push(op);
+      Op mo; mo.kind = OP_MODULATE; mo.kclass = RIB_KC_ELTWISE; mo.name = key + ".spade.modulate";
+      memset(&mo.mp, 0, sizeof mo.mp);
+      mo.mp.ksplit = S; mo.mp.B = B; mo.mp.npad = sg.npad; mo.mp.xmC = x.Cp; mo.mp.xm_ups = x_ups ? 1 : 0;
+      mo.mp.m_ld = nx.ld; mo.mp.C = sg.Cp; mo.mp.nsets = sg.nsets; mo.mp.act0 = act0 ? ACT_LRELU : ACT_NONE; mo.mp.act1 = ACT_NONE;
+      mo.mp.Hout = Hout; mo.mp.Wout = Wout;
+      mo.m_slab = WS(slab_off); mo.m_bias = WT(sg.b_off); mo.m_xm = WS(x.off); mo.m_sc = WS(nx.sc); mo.m_sh = WS(nx.sh);
+      mo.m_ys0 = WS(ys0->off); if (sg.nsets == 2) mo.m_ys1 = WS(ys1->off);
+      const size_t total = (size_t)Hout * Wout * (sg.nsets * sg.Cp / 4);
+      mo.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), B, 1);
+      push(mo);
+      return true;
+    }
     *ys0 = act(sg.C, Hout, Wout);
     if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
     Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = v;
@@ -562,7 +630,7 @@ struct Builder {
     op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + v->BN() - 1) / v->BN(), B);
     op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
     P->flops[RIB_KC_SPADE] += op.flops;
-    P->ops.push_back(op);
+    push(op);
     return true;
   }
 
@@ -598,6 +666,29 @@ struct Builder {
     return true;
   }
 
+  // one of the two stride-2 encoders of the mask network (generator.py:449-459); its last level
+  // lands in half of the concatenated tensor and of the concatenated (scale, shift) arrays
+  bool mask_branch(int b, const Act& input, const Act& CAT, const Norm& ncat, int chm) {
+    const rib_config& c = h->g.c;
+    const std::string m = "flow_network_temp";
+    const char* branches[2] = {"down_lbl", "down_img"};
+    Act cur = input; Norm ncur; bool have = false;
+    for (int i = 0; i <= c.mask_down; ++i) {
+      const ConvDef& cd = conv_of(h, m + "." + branches[b] + "." + std::to_string(i));
+      const bool lastl = (i == c.mask_down);
+      Act o = lastl ? CAT : act(cd.cout, i == 0 ? cur.H : cur.H / 2, i == 0 ? cur.W : cur.W / 2);
+      Norm no = lastl ? ncat : norm(pad8(cd.cout));
+      ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
+      if (have) { a.pro = &ncur; a.pro_lrelu = true; }
+      if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; }
+      a.want_stats = true; a.stats_out = &no; a.affine = true;
+      if (!conv(a, cd.name)) return false;
+      if (!lastl) tap(std::string("mask.") + (b == 0 ? "lbl_" : "img_") + std::to_string(i) + ".raw", o);
+      cur = o; ncur = no; have = true;
+    }
+    return true;
+  }
+
   bool build() {
     const Cfg& g = h->g;
     const rib_config& c = g.c;
@@ -615,28 +706,45 @@ struct Builder {
       op.k_s0 = US(s0); if (c1) op.k_s1 = US(s1);
       op.k_dst = WS(dst.off);
       op.grid = dim3((H * W + 255) / 256, B, 1);
-      P->ops.push_back(op);
+      push(op);
     };
     pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
-    pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
+    const int ev_label = record_after_last();   // also the fork point of the side streams
     pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
+    cur_stream = ST_EMBED; wait_before_next(ev_label);
+    pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
 
     // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
     std::vector<Act> cond(c.emb_down + 1);
+    std::vector<int> ev_cond(c.emb_down + 1, -1);
     {
       const ConvDef& cf = conv_of(h, "ref_embedding.conv_first");
       cond[0] = act(cf.cout, H, W);
       ConvArgs a; a.cd = &cf; a.in = Ein; a.out = cond[0]; a.act = ACT_LRELU;
       if (!conv(a, "ref_embedding.conv_first")) return false;
+      ev_cond[0] = record_after_last();
       tap("cond_0", cond[0]);
       for (int i = 0; i < c.emb_down; ++i) {
         const ConvDef& cd = conv_of(h, "ref_embedding.down_" + std::to_string(i));
         cond[i + 1] = act(cd.cout, cond[i].H / 2, cond[i].W / 2);
         ConvArgs b; b.cd = &cd; b.in = cond[i]; b.out = cond[i + 1]; b.act = ACT_LRELU;
         if (!conv(b, cd.name)) return false;
+        ev_cond[i + 1] = record_after_last();
         tap("cond_" + std::to_string(i + 1), cond[i + 1]);
       }
     }
+
+    // ---- label branch of the mask network (depends only on the label map): side stream ----
+    const std::string m = "flow_network_temp";
+    const int chm = g.mask_nf(c.mask_down);
+    const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
+    if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
+    Act CAT = act(2 * chm, Hm, Wm);
+    Norm ncat = norm(CAT.Cp);
+    cur_stream = ST_LABEL; wait_before_next(ev_label);
+    if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+    const int ev_lbl = record_after_last();
+    cur_stream = ST_MAIN;
 
     // ---- main generator (generator.py:201-228) ----
     Act x; Norm nx;
@@ -650,6 +758,7 @@ struct Builder {
     for (int i = 0; i <= D; ++i) {
       Act out; Norm nout;
       const bool last = (i == D);
+      wait_before_next(ev_cond[std::min(c.emb_down, i)]);
       if (!spade_block("down_" + std::to_string(i), x, false, nx, cond[std::min(c.emb_down, i)], &out, last ? &nout : nullptr)) return false;
       if (!last) {   // self.downsample = AvgPool2d(3, 2, 1) (generator.py:127,207-208)
         if (out.Cp % 4 != 0 || 256 % (out.Cp / 4) != 0) { error = "avgpool: unsupported channel count"; return false; }
@@ -663,14 +772,14 @@ struct Builder {
         op.pp.H = out.H; op.pp.W = out.W; op.pp.C = out.Cp; op.pp.blocks = blocks;
         op.p_x = WS(out.off); op.p_y = WS(pooled.off); op.p_stat = WS(part);
         op.grid = dim3(blocks, B, 1);
-        P->ops.push_back(op);
+        push(op);
         Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = op.name + ".stats";
         memset(&f.fp, 0, sizeof f.fp);
         f.fp.tiles = blocks; f.fp.Cs = out.Cp; f.fp.C = out.Cp; f.fp.ld = np.ld; f.fp.off = 0;
         f.fp.inv_count = 1.0f / ((float)pooled.H * (float)pooled.W); f.fp.eps = 1e-5f;
         f.f_part = WS(part); f.f_scale = WS(np.sc); f.f_shift = WS(np.sh);
         f.grid = dim3((out.Cp + 31) / 32, B, 1);
-        P->ops.push_back(f);
+        push(f);
         x = pooled; nx = np;
       } else { x = out; nx = nout; }
     }
@@ -695,31 +804,9 @@ struct Builder {
       if (!conv(a, "conv_img")) return false;
     }
 
-    // ---- MaskGenerator (generator.py:493-510) ----
-    const std::string m = "flow_network_temp";
-    const int chm = g.mask_nf(c.mask_down);
-    const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
-    if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
-    Act CAT = act(2 * chm, Hm, Wm);
-    Norm ncat = norm(CAT.Cp);
-    const char* branches[2] = {"down_lbl", "down_img"};
-    const Act* bin[2] = {&L, &I9};
-    for (int b = 0; b < 2; ++b) {
-      Act cur = *bin[b]; Norm ncur; bool have = false;
-      for (int i = 0; i <= c.mask_down; ++i) {
-        const ConvDef& cd = conv_of(h, m + "." + branches[b] + "." + std::to_string(i));
-        const bool lastl = (i == c.mask_down);
-        Act o = lastl ? CAT : act(cd.cout, i == 0 ? cur.H : cur.H / 2, i == 0 ? cur.W : cur.W / 2);
-        Norm no = lastl ? ncat : norm(pad8(cd.cout));
-        ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
-        if (have) { a.pro = &ncur; a.pro_lrelu = true; }
-        if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; }
-        a.want_stats = true; a.stats_out = &no; a.affine = true;
-        if (!conv(a, cd.name)) return false;
-        if (!lastl) tap(std::string("mask.") + (b == 0 ? "lbl_" : "img_") + std::to_string(i) + ".raw", o);
-        cur = o; ncur = no; have = true;
-      }
-    }
+    // ---- MaskGenerator (generator.py:493-510): image branch, then join with the label branch ----
+    if (!mask_branch(1, I9, CAT, ncat, chm)) return false;
+    wait_before_next(ev_lbl);
     tap("mask.cat.raw", CAT);
     Act r; bool first = true;
     for (int i = 0; i < c.mask_res_blocks; ++i) {
@@ -754,7 +841,7 @@ struct Builder {
       op.a_out = WS(o.off);
       const size_t total = (size_t)Hm * Wm * (o.Cp / 4);
       op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), B, 1);
-      P->ops.push_back(op);
+      push(op);
       tap("mask.res_" + std::to_string(i), o);
       r = o; first = false;
     }
@@ -814,8 +901,19 @@ struct Resolver {
   }
 };
 
-int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
+int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool single_stream = false) {
+  const bool multi = h->use_streams && !single_stream && h->side[ST_EMBED] != nullptr;
+  if (multi)
+    while ((int)h->events.size() < P->num_events) {
+      hipEvent_t e;
+      HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->events.push_back(e);
+    }
   for (Op& op : P->ops) {
+    // in single-stream mode the plan order is already a valid topological order
+    hipStream_t st = (multi && op.stream != ST_MAIN) ? h->side[op.stream] : caller;
+    if (multi)
+      for (int ev : op.wait_ev) HIP_TRY(h, hipStreamWaitEvent(st, h->events[ev], 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
       HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
@@ -837,6 +935,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
         p.part = R.get<const float>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
         p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
         hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(1024), 0, st, p);
+      } break;
+      case OP_MODULATE: {
+        ModulateParams p = op.mp;
+        p.slab = R.get<const float>(op.m_slab); p.bias = R.get<const float>(op.m_bias); p.xm = R.get<const float>(op.m_xm);
+        p.m_scale = R.get<const float>(op.m_sc); p.m_shift = R.get<const float>(op.m_sh);
+        p.ys0 = R.get<float>(op.m_ys0); p.ys1 = R.get<float>(op.m_ys1);
+        hipLaunchKernelGGL(k_spade_modulate, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_SPLITEPI: {
         SplitEpiParams p = op.sp;
@@ -867,6 +972,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st) {
       HIP_TRY(h, hipEventRecord(e1, st));
       h->prof_events.push_back({op.kclass, {e0, e1}});
     }
+    if (multi && op.record_ev >= 0) HIP_TRY(h, hipEventRecord(h->events[op.record_ev], st));
   }
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
@@ -913,7 +1019,11 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
   if (device >= 0) {   // device < 0: host-only handle (inventory, plans, weight fold; no launches)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float));
+    for (int i = 1; i < ST_COUNT && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = fmt("rib_create: device %d: %s", device, hipGetErrorString(e)); return RIB_ERR_HIP; }
+    // measured on MI355X at 512x512, batch 1: co-running the branches is SLOWER (4.07 vs 3.82 ms
+    // per frame), the concurrent kernels contend for the same CUs; kept as an opt-in
+    h->use_streams = getenv("RIB_STREAMS") != nullptr;
   }
   *out = h.release();
   return RIB_OK;
@@ -922,6 +1032,8 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 void rib_destroy(rib_handle* h) {
   if (!h) return;
   if (h->d_blob) (void)hipFree(h->d_blob);
+  for (int i = 1; i < ST_COUNT; ++i) if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+  for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   delete h;
 }
@@ -1261,17 +1373,17 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   Plan sub; sub.B = B; sub.H = H; sub.W = W;
   const std::string nm = op_name;
   for (const Op& op : P->ops)
-    if (op.name == nm || op.name == nm + ".splitk_sum") sub.ops.push_back(op);
+    if (op.name == nm || op.name == nm + ".splitk_sum" || op.name == nm + ".modulate") sub.ops.push_back(op);
   if (sub.ops.empty()) return fail(h, RIB_ERR_INVALID, fmt("rib_time_op: no op named '%s'", op_name));
   Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const bool was = h->profiling; h->profiling = false;
-  rc = run_plan(h, &sub, R, st);   // warm-up
+  rc = run_plan(h, &sub, R, st, true);   // warm-up
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
   HIP_TRY(h, hipEventRecord(e0, st));
-  for (int i = 0; i < iters && rc == RIB_OK; ++i) rc = run_plan(h, &sub, R, st);
+  for (int i = 0; i < iters && rc == RIB_OK; ++i) rc = run_plan(h, &sub, R, st, true);
   HIP_TRY(h, hipEventRecord(e1, st));
   HIP_TRY(h, hipEventSynchronize(e1));
   float ms = 0.f;

@@ -76,9 +76,10 @@ def main():
             best = (base, None, None)
             results = []
             for vi, g in enumerate(geoms):
-                if bool(g[9]) != (kclass == 1):
-                    continue
-                for ks in ([1] if kclass == 1 else [1, 2, 3, 4, 6, 8, 12, 16]):
+                if kclass == 0 and g[9]:
+                    continue            # SPADE-epilogue variants only serve SPADE ops
+                # a SPADE op may also run unfused: plain 1x1 variant (+ split-K) and a modulate kernel
+                for ks in ([1] if g[9] else [1, 2, 3, 4, 6, 8, 12, 16]):
                     lib.rib_set_choice(h, B, H, W, name.encode(), vi, ks)
                     t = timeit()
                     if t is None:

@@ -12,8 +12,10 @@ __global__ __launch_bounds__(256) void conv_like(const float* x, const float* w,
   __shared__ __attribute__((aligned(16))) float sA[IH * IW * CK];
   __shared__ __attribute__((aligned(16))) float sB[2][BN * CK];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-  const int tile = blockIdx.x, ty0 = (tile / tilesX) * 8, tx0 = (tile % tilesX) * 16;
   const int fy = wave * 2 + li / 16, fx = li % 16;
+  const int ntiles_total = (H / 8) * tilesX;
+  for (int tile = blockIdx.x; tile < ntiles_total; tile += gridDim.x) {
+  const int ty0 = (tile / tilesX) * 8, tx0 = (tile % tilesX) * 16;
   f32x16 acc, acc2;
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
   const int ac4 = tid % 8;
@@ -78,13 +80,16 @@ __global__ __launch_bounds__(256) void conv_like(const float* x, const float* w,
   } else {
     float t = 0.f;
     for (int r = 0; r < 16; ++r) t += acc[r] + acc2[r];
-    y[(size_t)blockIdx.x * 256 + tid] = t;
+    y[(size_t)tile * 256 + tid] = t;
+  }
+  __syncthreads();
   }
 }
 
 template <int FEAT>
-void run(const char* name, const float* x, const float* w, float* y, int H, int W, int Cin) {
-  const int tilesX = W / 16, tiles = (H / 8) * tilesX;
+void run(const char* name, const float* x, const float* w, float* y, int H, int W, int Cin, int grid = 0) {
+  const int tilesX = W / 16, tiles_all = (H / 8) * tilesX;
+  const int tiles = grid > 0 && grid < tiles_all ? grid : tiles_all;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
@@ -110,6 +115,11 @@ int main() {
     run<11>("+ per-chunk A staging (reg prefetch)", x, w, y, c.H, c.H, c.C);
     run<15>("+ epilogue stores (= real kernel)", x, w, y, c.H, c.H, c.C);
     run<5>("A staging + epilogue, tiny weights", x, w, y, c.H, c.H, c.C);
+    run<15>("real kernel, persistent grid 256", x, w, y, c.H, c.H, c.C, 256);
+    run<15>("real kernel, persistent grid 512", x, w, y, c.H, c.H, c.C, 512);
+    run<15>("real kernel, persistent grid 1024", x, w, y, c.H, c.H, c.C, 1024);
+    run<0>("bare loop, persistent grid 512", x, w, y, c.H, c.H, c.C, 512);
+    run<0>("bare loop, persistent grid 1024", x, w, y, c.H, c.H, c.C, 1024);
   }
   return 0;
 }
