@@ -122,13 +122,20 @@ def main():
     conv_tflops = flops["igemm"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     spade_ms = prof["spade"]["ms"] / nprof
     classes = {k: {"launches_per_step": v["launches"] / nprof, "ms_per_step": v["ms"] / nprof} for k, v in prof.items()}
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py:
+    # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); bench.py itself cannot read counters
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp) and (B, H, W) == (1, 512, 512):
+        with open(tp) as f:
+            traffic = json.load(f)["classes"]["igemm"]["hbm_bytes_per_launch"]
     roofline = {
         "bound": "mfma", "kernel": "k_igemm (fp32 MFMA implicit-GEMM convolution, %d launches/step)" % int(prof["igemm"]["launches"] / nprof),
         "achieved": conv_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": conv_tflops / PEAK_F32_MFMA_TFLOPS,
         "avg_launch_us": conv_ms * 1e3 / max(1.0, prof["igemm"]["launches"] / nprof),
         "algorithmic_gflop_per_step": flops["igemm"] / 1e9,
-        "traffic": None,
+        "traffic": traffic,
         "classes": classes,
         "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),

@@ -27,6 +27,8 @@ def plan_names(B, H, W):
     c = _native.RibConfig(**{n: getattr(spec, n) for n, _ in _native.RibConfig._fields_})
     h = C.c_void_p()
     assert lib.rib_create(C.byref(c), -1, C.byref(h)) == 0
+    from render_in_between_amd import tuning
+    tuning.apply(lib, h, tuning.load(), B, H, W)      # the same pinned choices Generator applies
     buf = C.create_string_buffer(512)
     out = []
     for i in range(lib.rib_num_launches(h, B, H, W)):
