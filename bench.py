@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--mode", choices=("frame", "chain"), default="frame",
+                    help="frame: one forward+blend per step (BASELINE configs[1], the default); "
+                         "chain: one autoregressive segment of --frames dependent frames per step (configs[2]/[3] shape)")
+    ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     args = ap.parse_args()
@@ -75,9 +79,19 @@ def main():
     # per-rank synthetic inputs (rank r renders its own frames)
     label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 1000 * rank)]
 
-    def step():
-        img, mask = G(label, None, fake, prev)
-        return G.blend(img, mask, fake)
+    frames_per_step = B
+    if args.mode == "chain":
+        T = args.frames
+        frames_per_step = B * T
+        labels = label.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+        dains = fake.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+
+        def step():
+            return G.chain(prev, labels, dains, want_all=False)[2]
+    else:
+        def step():
+            img, mask = G(label, None, fake, prev)
+            return G.blend(img, mask, fake)
 
     def log(msg):
         if rank == 0:
@@ -103,7 +117,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    fps = world * B * args.steps / dt
+    fps = world * frames_per_step * args.steps / dt
 
     if rank != 0:
         if world > 1:
@@ -118,6 +132,8 @@ def main():
     for _ in range(nprof):
         step()
     prof = G.profile_collect()
+    if args.mode == "chain":
+        nprof = nprof * args.frames          # per-forward averages
     conv_ms = prof["igemm"]["ms"] / nprof
     conv_tflops = flops["igemm"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     spade_ms = prof["spade"]["ms"] / nprof
@@ -138,14 +154,14 @@ def main():
         "traffic": traffic,
         "classes": classes,
         "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
-        "whole_step_frac_of_mfma_roof": (sum(flops.values()) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
+        "whole_step_frac_of_mfma_roof": (sum(flops.values()) * (frames_per_step / B) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
     }
 
     log("profile pass done: conv %.3f ms/step" % conv_ms)
     # ---- parity on the bench inputs + CPU baseline (oracle timed on the host cores) ----
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.mode == "frame":
         from oracle import generator_ref
         R = generator_ref.RefGenerator(spec, sd)
         torch.set_num_threads(min(16, os.cpu_count() or 1))   # 16 threads is the fastest setting on the 256-CPU GPU box (tools/cpu_threads.py sweep: 8/16/32/64/128)
@@ -171,8 +187,9 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%dx%d single-frame generator fwd + blend, batch=%d, fp32, seed-defined random-init "
-                               "HSM.yaml generator (spectral-norm vectors power-iterated)" % (H, W, B),
+        "config": {"workload": ("%dx%d single-frame generator fwd + blend, batch=%d, fp32" % (H, W, B) if args.mode == "frame" else
+                                "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, fp32" % (H, W, args.frames, B))
+                               + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
                    "frames_per_step_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), one RCCL weight broadcast" % world,
                    "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
