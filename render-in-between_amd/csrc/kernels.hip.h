@@ -50,6 +50,11 @@ struct IgemmParams {
   const float* pro_shift;
   int pro_ld;
   int pro_lrelu;
+  // optional second operand of a fused 1x1 convolution that accumulates into the same output
+  // (the learned shortcut of a residual block: out = conv3x3(y1) + conv1x1(ys) + bias):
+  // x2 [B][Hout][Wout][x2C], w2 [CoutPad][Cin2]; 3x3 stride-1 variants only
+  const float* x2; const float* w2;
+  int x2C, Cin2;
   // B operand: filters [CoutPad][taps][Cin] (Cin contiguous), bias [CoutPad]
   const float* w;
   const float* bias;
@@ -201,16 +206,46 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   };
   // fused prologue on the way into LDS: InstanceNorm affine + LeakyReLU; conv zero padding is
   // applied AFTER the transform (the reference pads the activated tensor)
-  auto writeA = [&]() {
+  auto writeA = [&](bool raw) {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
       int pix, iy, ix;
       const bool inb = slot_inb(i, pix, iy, ix);
       float4 v = areg[i];
-      if (p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
-      if (p.pro_lrelu) v = lrelu4(v);
+      if (!raw && p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
+      if (!raw && p.pro_lrelu) v = lrelu4(v);
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tid + i * 256 < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
+    }
+  };
+
+  // one tap of one chunk: (BK/8) x {fragment reads, MF*NF*4 MFMAs} on the shifted LDS window
+  auto compute_tap = [&](int dy, int dx, int buf) {
+    int aoff[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      int r, c;
+      if (UPS) { r = ((fy[mf] + dy - 1) >> 1) + 1; c = ((fx + dx - 1) >> 1) + 1; }
+      else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
+      aoff[mf] = (r * G::IW + c) * G::CK + lh * 4;
+    }
+    const float* sBb = sB + buf * G::SB + (wn * NF * 32 + li) * G::CK + lh * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      float4 a[MF], b[NF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + kb * 8);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
+        }
     }
   };
 
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   prefetchA(kc_begin);
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
     __syncthreads();   // every wave is done reading sA / sB of the previous chunk
-    writeA();
+    writeA(false);
 #pragma unroll 1
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int buf = tap & 1;
@@ -232,33 +267,43 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       // next storeB does not have to cover it
       if (tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
       __syncthreads();
-      const int dy = tap / KS, dx = tap % KS;
-      int aoff[MF];
+      compute_tap(tap / KS, tap % KS, buf);
+    }
+  }
+
+  // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----
+  if (KS == 3 && STRIDE == 1 && !UPS && !SPADE && p.x2 != nullptr && split == p.ksplit - 1) {
+    const float* x2n = p.x2 + (size_t)n * p.Hin * p.Win * p.x2C;
+    auto loadB2 = [&](int kc) {
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        int r, c;
-        if (UPS) { r = ((fy[mf] + dy - 1) >> 1) + 1; c = ((fx + dx - 1) >> 1) + 1; }
-        else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
-        aoff[mf] = (r * G::IW + c) * G::CK + lh * 4;
+      for (int i = 0; i < G::NB4; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < G::BN && n0 + row < p.CoutPad)
+          v = *reinterpret_cast<const float4*>(p.w2 + (size_t)(n0 + row) * p.Cin2 + kc + c4 * 4);
+        breg[i] = v;
       }
-      const float* sBb = sB + buf * G::SB + (wn * NF * 32 + li) * G::CK + lh * 4;
+    };
+    auto prefetchA2 = [&](int kc) {
 #pragma unroll
-      for (int kb = 0; kb < BK / 8; ++kb) {
-        float4 a[MF], b[NF];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + kb * 8);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-          for (int nf = 0; nf < NF; ++nf) {
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
-          }
+      for (int i = 0; i < NA4; ++i) {
+        int pix, iy, ix;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot_inb(i, pix, iy, ix))
+          v = *reinterpret_cast<const float4*>(x2n + ((size_t)iy * p.Win + ix) * p.x2C + kc + ac4 * 4);
+        areg[i] = v;
       }
+    };
+    loadB2(0);
+    prefetchA2(0);
+    for (int kc = 0; kc < p.Cin2; kc += BK) {
+      __syncthreads();
+      writeA(true);
+      storeB(0);
+      if (kc + BK < p.Cin2) { loadB2(kc + BK); prefetchA2(kc + BK); }
+      __syncthreads();
+      compute_tap(1, 1, 0);
     }
   }
 

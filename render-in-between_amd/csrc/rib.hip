@@ -55,6 +55,7 @@ struct ConvDef {
   bool used = true;
   // device blob offsets (floats), filled by finalize
   size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;
+  size_t fb_off = 0;   // conv_block_1 of a learned-shortcut SPADE block: bias + shortcut bias (fused launch)
   int cinp = 0, coutp = 0;
 };
 
@@ -194,13 +195,13 @@ const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
 
 Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
-                      int Cin, bool allow_split) {
+                      int Cin, bool allow_split, int Cin2 = 0) {
   Choice best;
   best.cycles = 1e300;
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
-    if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0) continue;
+    if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     const int BK = v.BK;
     const int nchunks = Cin / BK;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
@@ -257,7 +258,7 @@ struct Op {
   // igemm
   const Variant* var = nullptr;
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
-  PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab;
+  PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
   // split-K epilogue
   SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
   // unfused SPADE modulate
@@ -357,6 +358,9 @@ void assign_weight_layout(rib_handle* h) {
     c.w_off = take((size_t)c.coutp * c.ks * c.ks * c.cinp);
     c.b_off = take(c.coutp);
     if (c.in_affine) { c.g_off = take(c.coutp); c.be_off = take(c.coutp); }
+    if (c.spade_cond && c.name.size() > 13 && c.name.compare(c.name.size() - 13, 13, ".conv_block_1") == 0 &&
+        h->conv_index.count(c.name.substr(0, c.name.size() - 1) + "s"))
+      c.fb_off = take(c.coutp);
   }
   // SPADE groups: block_0 (+ block_s when the shortcut is learned) share one launch
   for (auto& c : h->convs) {
@@ -463,6 +467,7 @@ struct Builder {
     int cout_store = -1;    // columns stored (default: out slice padded width)
     int act = ACT_NONE;
     const Act* res = nullptr; bool res_ups = false;
+    const ConvDef* aux = nullptr; Act aux_in;   // fused 1x1 shortcut operand (accumulated into the same output)
     PRef y_nchw;            // optional NCHW copy
     PRef y_user;            // when set, y is this user tensor (yC = cout exactly)
     bool want_stats = false;
@@ -478,13 +483,14 @@ struct Builder {
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
-    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split);
+    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0);
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
         const bool ok = tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+                        (!a.aux || a.aux->cinp % tv.BK == 0) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
         ch.v = &tv; ch.ksplit = ts;
@@ -505,6 +511,14 @@ struct Builder {
     op.x = WS(a.in.off);
     if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
     op.w = WT(c.w_off); op.bias = WT(c.b_off);
+    double aux_flops = 0.0;
+    if (a.aux) {
+      if (c.ks != 3 || c.stride != 1 || a.ups || !c.fb_off || a.aux->ks != 1 || a.aux->coutp != c.coutp || a.aux_in.Cp != a.aux->cinp ||
+          a.aux_in.H != Hout || a.aux_in.W != Wout) { error = opname + ": fused shortcut operand does not fit"; return false; }
+      op.x2 = WS(a.aux_in.off); op.w2 = WT(a.aux->w_off); op.bias = WT(c.fb_off);
+      p.x2C = a.aux_in.Cp; p.Cin2 = a.aux->cinp;
+      aux_flops = 2.0 * a.aux->cin * a.aux->cout * (double)Hout * Wout * B;
+    }
     if (a.y_user.sp != PS_NULL) {
       op.y = a.y_user; p.yC = c.cout; p.yoff = 0; p.Cout = c.cout;
     } else {
@@ -517,7 +531,7 @@ struct Builder {
     int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
     op.grid = dim3(tiles, (c.coutp + v->BN() - 1) / v->BN(), B * S);
-    op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B;
+    op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B + aux_flops;
     P->flops[RIB_KC_IGEMM] += op.flops;
     if (S == 1) {
       if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
@@ -650,15 +664,20 @@ struct Builder {
     tap(name + ".h", hbuf);
     Act y1, dummy;
     if (!spade(name + ".1", cond, hbuf, false, nh, &y1, &dummy, true)) return false;
+    // learned shortcut (residual.py:98-108): its 1x1 convolution on SPADE_s(x) is fused into
+    // conv_block_1's launch as extra K chunks accumulating into the same output tile
+    const bool fuse_s = learned && !getenv("RIB_NO_FUSE_SHORTCUT");
     Act outs;
-    if (learned) {
+    if (learned && !fuse_s) {
       const ConvDef& cs = conv_of(h, name + ".conv_block_s");
       outs = act(cs.cout, Hout, Wout);
       ConvArgs a; a.cd = &cs; a.in = ys1; a.out = outs;
       if (!conv(a, name + ".conv_block_s")) return false;
     }
     *out = act(c1.cout, Hout, Wout);
-    { ConvArgs a; a.cd = &c1; a.in = y1; a.out = *out; a.res = learned ? &outs : &x;
+    { ConvArgs a; a.cd = &c1; a.in = y1; a.out = *out;
+      if (fuse_s) { a.aux = &conv_of(h, name + ".conv_block_s"); a.aux_in = ys1; }
+      else a.res = learned ? &outs : &x;
       a.res_ups = !learned && x_ups;   // identity shortcut of an upsampled input: x_up[y][x] = x[y>>1][x>>1]
       if (nout) { *nout = norm(out->Cp); a.want_stats = true; a.stats_out = nout; }
       if (!conv(a, name + ".conv_block_1")) return false; }
@@ -926,6 +945,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
         p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
         p.stat_part = R.get<float>(op.stat); p.slab = R.get<float>(op.slab);
+        p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
         hipLaunchKernelGGL(op.var->fn, op.grid, dim3(256), 0, st, p);
@@ -1112,6 +1132,11 @@ int rib_finalize_weights(rib_handle* h) {
       const std::vector<float>& bt = *tensor_data(h, c.name + ".layers.norm.bias");
       for (int o = 0; o < c.cout; ++o) { blob[c.g_off + o] = gm[o]; blob[c.be_off + o] = bt[o]; }
     }
+  }
+  for (auto& c : h->convs) {
+    if (!c.used || !c.fb_off) continue;
+    const ConvDef& cs = conv_of(h, c.name.substr(0, c.name.size() - 1) + "s");
+    for (int o = 0; o < c.cout; ++o) blob[c.fb_off + o] = blob[c.b_off + o] + blob[cs.b_off + o];
   }
   // SPADE gamma/beta filters: virtual column pairs [gamma(32) | beta(32)] per 32 virtual channels;
   // virtual channel v = set*Cp + c, set 0 = conv_block_0/1, set 1 = conv_block_s
