@@ -22,6 +22,7 @@
 namespace rib {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
@@ -95,7 +96,9 @@ struct IgemmGeom {
   static constexpr int IH = UPS ? (TH / 2 + 2) : ((TH - 1) * STRIDE + KS);
   static constexpr int IW = UPS ? (TW / 2 + 2) : ((TW - 1) * STRIDE + KS);
   static constexpr int CK = BK + 4;            // padded LDS row: conflict-free ds_read_b128
-  static constexpr int BN = 32 * NF * WN;
+  // NF == 0 selects the 16-column path (v_mfma_f32_16x16x4_f32) for layers with <= 16 output
+  // channels: no half-empty 32-column fragments
+  static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
   static constexpr int SA = IH * IW * CK;      // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
   static constexpr int NB4 = (BN * BK / 4 + 255) / 256;   // float4 filter loads per thread per tap
@@ -107,8 +110,11 @@ struct IgemmGeom {
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS> G;
+  constexpr bool N16 = (NF == 0);
+  constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(!SPADE || (NF % 2 == 0), "SPADE needs gamma/beta fragment pairs");
+  static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
+  static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0), "16-column path: 8x16-style tiles only");
   static_assert(!UPS || (STRIDE == 1 && KS == 3), "upsample gather only for 3x3 stride 1");
   static_assert(256 % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
@@ -143,13 +149,23 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) fy[mf] = (wm * MF + mf) * G::FRH + li / FRW;
 
-  f32x16 acc[MF][NF];
+  f32x16 acc[MF][NFE];
+  f32x4 acc16[MF][2];     // 16-column path: two 16-pixel sub-fragments (tile rows) per 32-pixel block
+  if (!N16) {
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+      for (int nf = 0; nf < NFE; ++nf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[mf][sub][r] = 0.f;
+  }
 
   const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
   const int wrow = G::TAPS * p.Cin;   // floats per filter row
@@ -221,6 +237,35 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 
   // one tap of one chunk: (BK/8) x {fragment reads, MF*NF*4 MFMAs} on the shifted LDS window
   auto compute_tap = [&](int dy, int dx, int buf) {
+    if constexpr (N16) {
+      // v_mfma_f32_16x16x4_f32: lane l holds A[pixel l&15][k = l>>4] and B[k = l>>4][column l&15];
+      // one float4 per lane (channels 4*(l>>4) .. +3 of a 16-channel step) feeds 4 MFMAs
+      const int l15 = lane & 15, lq = lane >> 4;
+      const float* sBb = sB + buf * G::SB + l15 * G::CK + lq * 4;
+#pragma unroll
+      for (int kb = 0; kb < BK / 16; ++kb) {
+        float4 a[MF][2];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            const int r = (wm * MF + mf) * 2 + sub + dy, c = l15 + dx;
+            a[mf][sub] = *reinterpret_cast<const float4*>(sA + (r * G::IW + c) * G::CK + lq * 4 + kb * 16);
+          }
+        const float4 b = *reinterpret_cast<const float4*>(sBb + kb * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+              const float av = t == 0 ? a[mf][sub].x : t == 1 ? a[mf][sub].y : t == 2 ? a[mf][sub].z : a[mf][sub].w;
+              const float bw = t == 0 ? b.x : t == 1 ? b.y : t == 2 ? b.z : b.w;
+              acc16[mf][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc16[mf][sub], 0, 0, 0);
+            }
+      }
+      return;
+    }
     int aoff[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
@@ -229,18 +274,18 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
       aoff[mf] = (r * G::IW + c) * G::CK + lh * 4;
     }
-    const float* sBb = sB + buf * G::SB + (wn * NF * 32 + li) * G::CK + lh * 4;
+    const float* sBb = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK + lh * 4;
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
-      float4 a[MF], b[NF];
+      float4 a[MF], b[NFE];
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + kb * 8);
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
+      for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFE; ++nf) {
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
@@ -309,7 +354,47 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 
   // ------------------------------------ epilogue ------------------------------------
   // accumulator element r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5)  (pixel), col = l&31 (channel)
-  if (!SPADE && p.slab != nullptr) {
+  if constexpr (N16) {
+    // accumulator element r of lane l: pixel x = (l>>4)*4 + r of tile row (block, sub), column l&15
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int col = n0 + l15;
+    const bool cvalid = col < p.Cout;
+    const float bv = p.bias[min(col, p.CoutPad - 1)];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oy = ty0 + (wm * MF + mf) * 2 + sub;
+          const int ox = tx0 + lq * 4 + r;
+          const float v = apply_act(acc16[mf][sub][r] + bv, p.act);
+          if (cvalid && oy < p.Hout && ox < p.Wout) {
+            const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+            p.y[pix * p.yC + p.yoff + col] = v;
+            if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+    if (p.stat_part) {
+      __syncthreads();
+      float* red = smem;   // [WM][16][2]
+      float a1 = s1 + __shfl_xor(s1, 16); a1 += __shfl_xor(a1, 32);
+      float a2 = s2 + __shfl_xor(s2, 16); a2 += __shfl_xor(a2, 32);
+      if (lane < 16) { red[(wm * 16 + l15) * 2] = a1; red[(wm * 16 + l15) * 2 + 1] = a2; }
+      __syncthreads();
+      if (tid < 16) {
+        float b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) { b1 += red[(m * 16 + tid) * 2]; b2 += red[(m * 16 + tid) * 2 + 1]; }
+        float* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
+        dst[n0 + tid] = b1;
+        dst[p.CoutPad + n0 + tid] = b2;
+      }
+    }
+  } else if (!SPADE && p.slab != nullptr) {
     // split-K: raw partial sums to slab [split][B][Hout][Wout][CoutPad]; k_splitk_epilogue finishes
     float* slab = p.slab + ((size_t)split * gridDim.z / p.ksplit + n) * p.Hout * p.Wout * p.CoutPad;
 #pragma unroll

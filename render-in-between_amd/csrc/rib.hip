@@ -38,7 +38,9 @@ std::string fmt(const char* f, ...) {
   return buf;
 }
 
-inline int pad8(int c) { return (c + 7) / 8 * 8; }
+// channel padding of an activation: 8, 16, or a multiple of 32 (so that every tensor admits the
+// 16- or 32-channel K chunks of the fast kernel variants; the 22-channel label map becomes 32)
+inline int pad8(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : (c + 31) / 32 * 32); }
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 inline int pick_bk(int cp) { return cp % 32 == 0 ? 32 : (cp % 16 == 0 ? 16 : 8); }
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
@@ -148,7 +150,7 @@ struct Variant {
   IgemmFn fn;
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
-  int BN() const { return 32 * NF * WN; }
+  int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
     const int ih = UPS ? TH() / 2 + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() / 2 + 2 : (TW() - 1) * STRIDE + KS;
     return (ih * iw * (BK + 4) + 2 * BN() * (BK + 4)) * 4;
@@ -167,6 +169,9 @@ const Variant kVariants[] = {
     RIB_V(8, 2, 2, 1, 1, 16, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 1, 3, false, false),
     // 3x3 stride 1, 16x16 tile (two fragments per wave)
     RIB_V(16, 4, 1, 2, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 16, 1, 3, false, false),
+    // 3x3 stride 1, 16-column path (v_mfma_f32_16x16x4_f32) for <= 16 output channels
+    RIB_V(16, 4, 1, 1, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 0, 32, 1, 3, false, false),
+    RIB_V(16, 4, 1, 2, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 0, 32, 1, 3, false, false),
     // 3x3 stride 2
     RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
     RIB_V(8, 2, 2, 1, 1, 16, 2, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 2, 3, false, false),
@@ -195,24 +200,25 @@ const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
 
 Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
-                      int Cin, bool allow_split, int Cin2 = 0) {
+                      int Cin, bool allow_split, int Cin2 = 0, bool allow_n16 = false) {
   Choice best;
   best.cycles = 1e300;
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
+    if (v.NF == 0 && !allow_n16) continue;
     const int BK = v.BK;
     const int nchunks = Cin / BK;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
-    const long ntiles = (ncols + v.BN() - 1) / v.BN();
+    const long ntiles = v.NF == 0 ? 1 : (ncols + v.BN() - 1) / v.BN();
     const int occ = std::max(1, std::min(v.MF * v.NF >= 4 ? 4 : 6, 160 * 1024 / v.lds_bytes()));
     for (int S : kSplits) {
-      if (S > nchunks || (S > 1 && !allow_split)) break;
+      if (S > nchunks || (S > 1 && (!allow_split || v.NF == 0))) break;
       const long wgs = tiles * ntiles * B * S;
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ks * ks;
-      const double mfma_tap = (BK / 8) * v.MF * v.NF * 4 * 64.0;
+      const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0;
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
       // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
@@ -483,14 +489,16 @@ struct Builder {
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
-    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0);
+    // the 16-column path serves layers with <= 16 output channels and no residual read
+    const bool can_n16 = c.cout <= 16 && !a.res && !getenv("RIB_NO_N16");
+    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
         const bool ok = tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
-                        (!a.aux || a.aux->cinp % tv.BK == 0) &&
+                        (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
         ch.v = &tv; ch.ksplit = ts;
@@ -530,7 +538,7 @@ struct Builder {
     op.y_nchw = a.y_nchw;
     int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
-    op.grid = dim3(tiles, (c.coutp + v->BN() - 1) / v->BN(), B * S);
+    op.grid = dim3(tiles, v->NF == 0 ? 1 : (c.coutp + v->BN() - 1) / v->BN(), B * S);
     op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B + aux_flops;
     P->flops[RIB_KC_IGEMM] += op.flops;
     if (S == 1) {

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void conv_like(const float* x, const float* w,
   auto loadB = [&](int kc, int tap) {
     const int row = tid / 8;
     if (FEAT & 2) breg = *reinterpret_cast<const float4*>(w + (size_t)(row % 32) * wrow + tap * Cin + kc + ac4 * 4);
+    else if (FEAT & 32) breg = *reinterpret_cast<const float4*>(w + ((tap * 7 + kc + blockIdx.x) % 64) * 1024 + tid * 4);
     else breg = *reinterpret_cast<const float4*>(w + ((tap * 7 + kc) % 64) * 1024 + tid * 4);
   };
   auto prefetchA = [&](int kc) {
@@ -111,6 +112,8 @@ int main() {
   for (auto c : cases) {
     run<0>("bare loop (tiny L2 weights, no A staging)", x, w, y, c.H, c.H, c.C);
     run<8>("+ per-tap window offsets", x, w, y, c.H, c.H, c.C);
+    run<32>("bare loop, per-WG staggered weight blocks", x, w, y, c.H, c.H, c.C);
+    run<32>("bare staggered, persistent grid 1024", x, w, y, c.H, c.H, c.C, 1024);
     run<10>("+ real strided weight loads", x, w, y, c.H, c.H, c.C);
     run<11>("+ per-chunk A staging (reg prefetch)", x, w, y, c.H, c.H, c.C);
     run<15>("+ epilogue stores (= real kernel)", x, w, y, c.H, c.H, c.C);
