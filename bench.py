@@ -44,6 +44,9 @@ def main():
                     help="frame: one forward+blend per step (BASELINE configs[1], the default); "
                          "chain: one autoregressive segment of --frames dependent frames per step (configs[2]/[3] shape)")
     ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent frames in flight per GPU: each on its own HIP stream with its own handle and "
+                         "workspace (segments between key frames are independent, SURVEY F9); every forward stays batch=B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     args = ap.parse_args()
@@ -58,10 +61,13 @@ def main():
     import render_in_between_amd as rib
     from render_in_between_amd import synth, distributed as ribdist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RIB_BENCH_DEVICE / RIB_DIST_BACKEND exist only to exercise the multi-rank path on a 1-GPU box
+    # (all ranks on one device, gloo instead of RCCL); the driver's multi-GPU runs use neither.
+    dev_index = int(os.environ.get("RIB_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        ribdist.init_process_group()
+        ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"))
 
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
@@ -79,6 +85,15 @@ def main():
     # per-rank synthetic inputs (rank r renders its own frames)
     label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 1000 * rank)]
 
+    # extra in-flight lanes: clones of the generator (same folded weight blob) on their own streams
+    lanes = [(G, torch.cuda.current_stream(dev))]
+    if args.inflight > 1:
+        blob = G.export_weights()
+        torch.cuda.synchronize(dev)
+        for _ in range(args.inflight - 1):
+            lanes.append((rib.Generator(cfg, device=dev).eval().import_weights(blob), torch.cuda.Stream(device=dev)))
+        torch.cuda.synchronize(dev)
+
     frames_per_step = B
     if args.mode == "chain":
         T = args.frames
@@ -86,27 +101,31 @@ def main():
         labels = label.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
         dains = fake.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
 
-        def step():
-            return G.chain(prev, labels, dains, want_all=False)[2]
+        def step(i=0):
+            g, st = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                return g.chain(prev, labels, dains, want_all=False)[2]
     else:
-        def step():
-            img, mask = G(label, None, fake, prev)
-            return G.blend(img, mask, fake)
+        def step(i=0):
+            g, st = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                img, mask = g(label, None, fake, prev)
+                return g.blend(img, mask, fake)
 
     def log(msg):
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     log("weights ready, warming up")
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, len(lanes))):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -191,7 +210,8 @@ def main():
                                 "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, fp32" % (H, W, args.frames, B))
                                + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
                    "frames_per_step_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), one RCCL weight broadcast" % world,
-                   "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1},
+                   "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1,
+                   "frames_in_flight_per_gpu": len(lanes)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
     print(json.dumps(line))

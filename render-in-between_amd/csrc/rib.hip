@@ -169,17 +169,21 @@ const Variant kVariants[] = {
     RIB_V(8, 2, 2, 1, 1, 16, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 1, 3, false, false),
     // 3x3 stride 1, 16x16 tile (two fragments per wave)
     RIB_V(16, 4, 1, 2, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 16, 1, 3, false, false),
+    RIB_V(16, 4, 1, 2, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 32, 1, 3, false, false),
+    RIB_V(16, 4, 1, 1, 4, 16, 1, 3, false, false),
     // 3x3 stride 1, 16-column path (v_mfma_f32_16x16x4_f32) for <= 16 output channels
     RIB_V(16, 4, 1, 1, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 0, 32, 1, 3, false, false),
     RIB_V(16, 4, 1, 2, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 0, 32, 1, 3, false, false),
     // 3x3 stride 2
     RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
     RIB_V(8, 2, 2, 1, 1, 16, 2, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 2, 3, false, false),
-    RIB_V(16, 4, 1, 1, 1, 16, 2, 3, false, false),
+    RIB_V(16, 4, 1, 1, 1, 16, 2, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 2, 3, false, false),
+    RIB_V(8, 2, 2, 2, 1, 16, 2, 3, false, false),
     // 3x3 on a nearest-x2-upsampled input
     RIB_V(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 32, 1, 3, true, false),
     RIB_V(16, 4, 1, 1, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 16, 1, 3, true, false),
-    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, true, false),
+    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 2, 1, 32, 1, 3, true, false),
+    RIB_V(16, 4, 1, 2, 2, 32, 1, 3, true, false),
     // 1x1
     RIB_V(16, 4, 1, 1, 1, 16, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 1, false, false),
     RIB_V(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, false),
@@ -188,7 +192,8 @@ const Variant kVariants[] = {
     // SPADE: 1x1 gamma/beta GEMM on the condition map + modulate epilogue
     RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_V(8, 1, 4, 1, 2, 32, 1, 1, false, true),
     RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_V(8, 2, 2, 1, 2, 64, 1, 1, false, true),
-    RIB_V(16, 4, 1, 1, 4, 32, 1, 1, false, true),
+    RIB_V(16, 4, 1, 1, 4, 32, 1, 1, false, true),  RIB_V(16, 4, 1, 2, 2, 32, 1, 1, false, true),
+    RIB_V(16, 4, 1, 2, 2, 64, 1, 1, false, true),
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

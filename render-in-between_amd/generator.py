@@ -129,6 +129,16 @@ class Generator:
         _native.check(self._h, self._lib.rib_export_weights(self._h, _ptr(buf), n, self._stream()))
         return buf
 
+    def clone(self) -> "Generator":
+        """A second handle on the same device with the same folded weights (device-to-device copy
+        of the blob): used to keep several independent segments in flight on separate HIP streams
+        (a handle is single-stream)."""
+        g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning)
+        blob = self.export_weights()
+        g.import_weights(blob)
+        torch.cuda.current_stream(self.device).synchronize()
+        return g
+
     def weights_numel(self) -> int:
         return self._lib.rib_weights_bytes(self._h) // 4
 

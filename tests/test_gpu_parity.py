@@ -213,7 +213,7 @@ def test_driver_on_gpu_matches_oracle_loop(tmp_path):
     spec, sd, G = build("full", 0)
     cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=32, model_width=48, gauss_sigma=5,
                        skeleton_thres=0.001, foot_thres=0.001)
-    E = ev.Evaluator(cfg)
+    E = ev.Evaluator(cfg, lanes=1)
     out = os.path.join(root, "o", "Generated_frames")
     written = E.evaluate_from_folder(G, os.path.join(root, "inputs"), os.path.join(root, "DAIN"),
                                      os.path.join(root, "Predict_motion"), out)
@@ -229,3 +229,22 @@ def test_driver_on_gpu_matches_oracle_loop(tmp_path):
         want = generator_ref.quantise_uint8(prev).astype(int)
         got = np.asarray(Image.open(written[i])).astype(int)
         assert np.abs(got - want).max() <= 1 and (got != want).mean() < 2e-3, i
+
+
+def test_driver_lanes_are_bit_identical(tmp_path):
+    """Several segments in flight on separate streams/handles give exactly the single-lane frames."""
+    import numpy as np
+    from PIL import Image
+    from render_in_between_amd import evaluator as ev
+    from tests.test_driver import _write_example
+    root = str(tmp_path)
+    n = _write_example(root, n_key=4, rate=2, H=32, W=48)        # 3 independent segments
+    spec, sd, G = build("full", 0)
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=32, model_width=48, gauss_sigma=5,
+                       skeleton_thres=0.001, foot_thres=0.001)
+    dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
+    a = ev.Evaluator(cfg, lanes=1).evaluate_from_folder(G, *dirs, os.path.join(root, "a"))
+    b = ev.Evaluator(cfg, lanes=3).evaluate_from_folder(G, *dirs, os.path.join(root, "b"))
+    assert len(a) == len(b) == n == 7
+    for fa, fb in zip(a, b):
+        assert np.array_equal(np.asarray(Image.open(fa)), np.asarray(Image.open(fb))), fa
