@@ -328,7 +328,8 @@ struct rib_handle {
   // side streams (forked from / joined to the caller's stream with events) and the event pool
   hipStream_t side[ST_COUNT] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> events;
-  bool use_streams = true;
+  std::vector<hipStream_t> stream_pool;
+  bool use_streams = false;
   // profiling
   bool profiling = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -1052,11 +1053,20 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
   if (device >= 0) {   // device < 0: host-only handle (inventory, plans, weight fold; no launches)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float));
-    for (int i = 1; i < ST_COUNT && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
+    // Side streams are opt-in (RIB_STREAMS="i,j" picks two of a small pool for the condition encoder
+    // and the label branch): HIP multiplexes streams onto a few hardware queues and a side stream
+    // that lands on the caller's queue only adds event traffic (stream_overlap_probe.py).
+    if (const char* sel = getenv("RIB_STREAMS")) {
+      int a = 1, b = 2;
+      sscanf(sel, "%d,%d", &a, &b);
+      for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+        hipStream_t st;
+        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        h->stream_pool.push_back(st);
+      }
+      if (e == hipSuccess && a >= 0 && a < 6 && b >= 0 && b < 6) { h->side[ST_EMBED] = h->stream_pool[a]; h->side[ST_LABEL] = h->stream_pool[b]; h->use_streams = true; }
+    } else h->use_streams = false;
     if (e != hipSuccess) { g_create_error = fmt("rib_create: device %d: %s", device, hipGetErrorString(e)); return RIB_ERR_HIP; }
-    // measured on MI355X at 512x512, batch 1: co-running the branches is SLOWER (4.07 vs 3.82 ms
-    // per frame), the concurrent kernels contend for the same CUs; kept as an opt-in
-    h->use_streams = getenv("RIB_STREAMS") != nullptr;
   }
   *out = h.release();
   return RIB_OK;
@@ -1065,7 +1075,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 void rib_destroy(rib_handle* h) {
   if (!h) return;
   if (h->d_blob) (void)hipFree(h->d_blob);
-  for (int i = 1; i < ST_COUNT; ++i) if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+  for (hipStream_t st : h->stream_pool) (void)hipStreamDestroy(st);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   delete h;
