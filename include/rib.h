@@ -88,6 +88,14 @@ size_t rib_weights_bytes(const rib_handle* h);
 int rib_export_weights(rib_handle* h, void* dst_device, size_t bytes, void* hip_stream);
 int rib_import_weights(rib_handle* h, const void* src_device, size_t bytes, void* hip_stream);
 
+/* ---- arithmetic of the matrix-core contractions (no reference counterpart: the reference is fp32
+ * only).  RIB_DTYPE_F32 (default): exact-fp32 MFMA, the mode every parity claim and the bench
+ * headline are made in.  RIB_DTYPE_BF16 (BASELINE.json configs[2]): operands rounded to bf16 at the
+ * matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulation; activations, InstanceNorm statistics,
+ * SPADE modulation and all epilogues stay fp32.  Takes effect on the next forward. ---- */
+enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1 };
+int rib_set_compute_dtype(rib_handle* h, int dtype);
+
 /* ---- forward: replaces  img, mask = net_G(label, label_prev, img_fake, img_prev)
  *      (PGNR/models/generator.py:181-234; call site PGNR/models/evaluator.py:255) ----
  * label [B,label_nc,H,W], img_fake/img_prev [B,image_nc,H,W] -> img [B,image_nc,H,W] (tanh),

@@ -23,6 +23,15 @@ namespace rib {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive fp32 values -> one bf16 MFMA operand (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 to_bf16x8(const float4 lo, const float4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+  r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+  return r;
+}
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
@@ -71,6 +80,8 @@ struct IgemmParams {
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
   float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
+  int bf16;              // 1: bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on fp32 LDS tiles, fp32 accumulate;
+                         //    storage, statistics and every epilogue stay fp32 (BASELINE config 3 mode)
   int ksplit;            // >= 1: K is split over blockIdx.z
   float* slab;           // when set: raw partial sums go to [ksplit][B][Hout][Wout][CoutPad] instead of y
   // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
@@ -266,22 +277,48 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       }
       return;
     }
-    int aoff[MF];
+    int aoff[MF];   // LDS float offset of this lane's pixel in the (dy, dx) window
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       int r, c;
       if (UPS) { r = ((fy[mf] + dy - 1) >> 1) + 1; c = ((fx + dx - 1) >> 1) + 1; }
       else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
-      aoff[mf] = (r * G::IW + c) * G::CK + lh * 4;
+      aoff[mf] = (r * G::IW + c) * G::CK;
     }
-    const float* sBb = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK + lh * 4;
+    const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
+    if constexpr (BK % 16 == 0) {
+      if (p.bf16) {
+        // v_mfma_f32_32x32x16_bf16: lane (row/col = l&31, half h = l>>5) holds k = 8h .. 8h+7 of a
+        // 16-channel step: 32 contiguous bytes of the same fp32 LDS rows the fp32 path reads
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+          bf16x8 a[MF], b[NFE];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const float* q = sA + aoff[mf] + kb * 16 + lh * 8;
+            a[mf] = to_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+          }
+#pragma unroll
+          for (int nf = 0; nf < NFE; ++nf) {
+            const float* q = sBrow + nf * 32 * G::CK + kb * 16 + lh * 8;
+            b[nf] = to_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+          }
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NFE; ++nf)
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       float4 a[MF], b[NFE];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + kb * 8);
+      for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + lh * 4 + kb * 8);
 #pragma unroll
-      for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBb + nf * 32 * G::CK + kb * 8);
+      for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll

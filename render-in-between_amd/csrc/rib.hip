@@ -322,6 +322,7 @@ struct rib_handle {
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
   bool weights_ready = false;
+  bool compute_bf16 = false;   // rib_set_compute_dtype
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
@@ -958,6 +959,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x = R.get<const float>(op.x); p.pro_scale = R.get<const float>(op.pro_scale); p.pro_shift = R.get<const float>(op.pro_shift);
         p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
         p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
+        p.bf16 = h->compute_bf16 ? 1 : 0;
         p.stat_part = R.get<float>(op.stat); p.slab = R.get<float>(op.slab);
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
@@ -1210,6 +1212,12 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
   if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
   HIP_TRY(h, hipMemcpyAsync(h->d_blob, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
   h->weights_ready = true;
+  return RIB_OK;
+}
+
+int rib_set_compute_dtype(rib_handle* h, int dtype) {
+  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
+  h->compute_bf16 = dtype == RIB_DTYPE_BF16;
   return RIB_OK;
 }
 

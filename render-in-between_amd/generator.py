@@ -28,7 +28,12 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Generator:
-    def __init__(self, gen_cfg, device=None, use_tuning=True):
+    def __init__(self, gen_cfg, device=None, use_tuning=True, compute_dtype="f32"):
+        """compute_dtype: 'f32' (exact-fp32 matrix cores; the reference's arithmetic) or 'bf16'
+        (bf16 matrix-core operands, fp32 accumulate / statistics / storage; BASELINE config 3)."""
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = compute_dtype
         self.spec = GenSpec.from_cfg(gen_cfg)
         self._tuning = None
         self._use_tuning = use_tuning
@@ -59,6 +64,7 @@ class Generator:
             raise (NotImplementedError if rc == -2 else _native.RibError)(
                 *(("rib_create: " + msg.decode(),) if rc == -2 else (rc, msg.decode())))
         self._h = h
+        _native.check(h, self._lib.rib_set_compute_dtype(h, 1 if compute_dtype == "bf16" else 0))
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.training = False
 
@@ -133,7 +139,7 @@ class Generator:
         """A second handle on the same device with the same folded weights (device-to-device copy
         of the blob): used to keep several independent segments in flight on separate HIP streams
         (a handle is single-stream)."""
-        g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning)
+        g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning, compute_dtype=self.compute_dtype)
         blob = self.export_weights()
         g.import_weights(blob)
         torch.cuda.current_stream(self.device).synchronize()
