@@ -77,8 +77,13 @@ def spade_res_block(sd, name, x, cond, taps=None):
     strings residual.py:82-108; _BaseConvBlock.forward conv.py:77-91)."""
     w0, b0 = conv_weight(sd, name + ".conv_block_0")
     w1, b1 = conv_weight(sd, name + ".conv_block_1")
-    h = F.conv2d(lrelu(spade(sd, name + ".conv_block_0", x, cond)), w0, b0, padding=1)
-    dx = F.conv2d(lrelu(spade(sd, name + ".conv_block_1", h, cond)), w1, b1, padding=1)
+    ys0 = lrelu(spade(sd, name + ".conv_block_0", x, cond))
+    h = F.conv2d(ys0, w0, b0, padding=1)
+    y1 = lrelu(spade(sd, name + ".conv_block_1", h, cond))
+    dx = F.conv2d(y1, w1, b1, padding=1)
+    if taps is not None:
+        taps[name + ".ys0"] = ys0
+        taps[name + ".y1"] = y1
     if (name + ".conv_block_s.layers.conv.bias") in sd:
         ws, bs = conv_weight(sd, name + ".conv_block_s")
         xs = F.conv2d(spade(sd, name + ".conv_block_s", x, cond), ws, bs)   # 'NC': no activation

@@ -80,8 +80,9 @@ struct IgemmParams {
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
   float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
-  int bf16;              // 1: bf16 matrix cores (v_mfma_f32_32x32x16_bf16) on fp32 LDS tiles, fp32 accumulate;
-                         //    storage, statistics and every epilogue stay fp32 (BASELINE config 3 mode)
+  // (the bf16 matrix-core mode, v_mfma_f32_32x32x16_bf16 on the same fp32 LDS tiles with fp32
+  // accumulate / statistics / storage, is the BF16 template flag: a runtime switch inside the tap
+  // loop cost the fp32 kernels 8 % through register pressure)
   int ksplit;            // >= 1: K is split over blockIdx.z
   float* slab;           // when set: raw partial sums go to [ksplit][B][Hout][Wout][CoutPad] instead of y
   // --- SPADE epilogue (template SPADE): out_s = act_s( (xm*scale+shift)*(1+gamma)+beta ) ---
@@ -118,7 +119,7 @@ struct IgemmGeom {
   static constexpr int TAPS = KS * KS;
 };
 
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE>
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS> G;
   constexpr bool N16 = (NF == 0);
@@ -286,8 +287,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       aoff[mf] = (r * G::IW + c) * G::CK;
     }
     const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
-    if constexpr (BK % 16 == 0) {
-      if (p.bf16) {
+    static_assert(!BF16 || (BK % 16 == 0 && NF > 0), "bf16 matrix-core path: 16-channel steps, 32-column fragments");
+    if constexpr (BF16) {
+      {
         // v_mfma_f32_32x32x16_bf16: lane (row/col = l&31, half h = l>>5) holds k = 8h .. 8h+7 of a
         // 16-channel step: 32 contiguous bytes of the same fp32 LDS rows the fp32 path reads
 #pragma unroll

@@ -148,6 +148,7 @@ typedef void (*IgemmFn)(const IgemmParams);
 struct Variant {
   int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
   IgemmFn fn;
+  bool BF16 = false;   // bf16 matrix-core twin of the same geometry
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
@@ -157,7 +158,9 @@ struct Variant {
   }
 };
 #define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
-  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP>}
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
+#define RIB_VB(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true}
 
 const Variant kVariants[] = {
     // 3x3 stride 1, tile 8x16 (4 waves along M), BN 32 / 64
@@ -194,6 +197,18 @@ const Variant kVariants[] = {
     RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_V(8, 2, 2, 1, 2, 64, 1, 1, false, true),
     RIB_V(16, 4, 1, 1, 4, 32, 1, 1, false, true),  RIB_V(16, 4, 1, 2, 2, 32, 1, 1, false, true),
     RIB_V(16, 4, 1, 2, 2, 64, 1, 1, false, true),
+    // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
+    // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
+    RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
+    RIB_VB(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 32, 1, 3, false, false),
+    RIB_VB(8, 2, 2, 1, 1, 32, 1, 3, false, false),  RIB_VB(8, 2, 2, 1, 1, 16, 1, 3, false, false),
+    RIB_VB(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_VB(8, 2, 2, 1, 1, 16, 2, 3, false, false),
+    RIB_VB(8, 2, 2, 1, 2, 16, 2, 3, false, false),
+    RIB_VB(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_VB(16, 4, 1, 1, 2, 32, 1, 3, true, false),
+    RIB_VB(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_VB(16, 4, 1, 1, 2, 32, 1, 1, false, false),
+    RIB_VB(16, 4, 1, 1, 2, 64, 1, 1, false, false), RIB_VB(8, 2, 2, 1, 1, 64, 1, 1, false, false),
+    RIB_VB(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_VB(16, 4, 1, 1, 2, 64, 1, 1, false, true),
+    RIB_VB(8, 2, 2, 1, 2, 64, 1, 1, false, true),
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -204,8 +219,21 @@ const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // A split-K launch pays a second (slab-summing) kernel.
 struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
 
-Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+                         int Cin, bool allow_split, int Cin2, bool allow_n16);
+
+// bf16 handles prefer a bf16 twin and fall back to the fp32 kernels where none exists
+Choice choose_variant(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                       int Cin, bool allow_split, int Cin2 = 0, bool allow_n16 = false) {
+  if (bf16) {
+    Choice c = choose_variant_dt(true, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16);
+    if (c.v) return c;
+  }
+  return choose_variant_dt(false, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16);
+}
+
+Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+                         int Cin, bool allow_split, int Cin2, bool allow_n16) {
   Choice best;
   best.cycles = 1e300;
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -213,6 +241,7 @@ Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B
     const Variant& v = kVariants[i];
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     if (v.NF == 0 && !allow_n16) continue;
+    if (v.BF16 != bf16) continue;
     const int BK = v.BK;
     const int nchunks = Cin / BK;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
@@ -223,7 +252,8 @@ Choice choose_variant(int stride, int ks, bool ups, bool spade, int ncols, int B
       const long wgs = tiles * ntiles * B * S;
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ks * ks;
-      const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0;
+      const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0
+                                        : (v.BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
       // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
@@ -498,7 +528,7 @@ struct Builder {
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
     // the 16-column path serves layers with <= 16 output channels and no residual read
     const bool can_n16 = c.cout <= 16 && !a.res && !getenv("RIB_NO_N16");
-    Choice ch = choose_variant(c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
+    Choice ch = choose_variant(h->compute_bf16, c.stride, c.ks, a.ups, false, c.coutp, B, Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
@@ -596,10 +626,10 @@ struct Builder {
     // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
     // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
     // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
-    const Variant* v = choose_variant(1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    const Variant* v = choose_variant(h->compute_bf16, 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
     Choice uf;   // unfused candidate
     const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
-    if (small_map) uf = choose_variant(1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
+    if (small_map) uf = choose_variant(h->compute_bf16, 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
     bool unfused = small_map && uf.v != nullptr;
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
@@ -672,6 +702,7 @@ struct Builder {
     const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
     Act ys0, ys1;
     if (!spade(name + ".0", cond, x, x_ups, nx, &ys0, &ys1, true)) return false;
+    tap(name + ".ys0", ys0);
     Act hbuf = act(c0.cout, Hout, Wout);
     Norm nh = norm(hbuf.Cp);
     { ConvArgs a; a.cd = &c0; a.in = ys0; a.out = hbuf; a.want_stats = true; a.stats_out = &nh;
@@ -679,6 +710,7 @@ struct Builder {
     tap(name + ".h", hbuf);
     Act y1, dummy;
     if (!spade(name + ".1", cond, hbuf, false, nh, &y1, &dummy, true)) return false;
+    tap(name + ".y1", y1);
     // learned shortcut (residual.py:98-108): its 1x1 convolution on SPADE_s(x) is fused into
     // conv_block_1's launch as extra K chunks accumulating into the same output tile
     const bool fuse_s = learned && !getenv("RIB_NO_FUSE_SHORTCUT");
@@ -959,7 +991,6 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x = R.get<const float>(op.x); p.pro_scale = R.get<const float>(op.pro_scale); p.pro_shift = R.get<const float>(op.pro_shift);
         p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
         p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
-        p.bf16 = h->compute_bf16 ? 1 : 0;
         p.stat_part = R.get<float>(op.stat); p.slab = R.get<float>(op.slab);
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
@@ -1217,6 +1248,7 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
   if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
+  if (h->compute_bf16 != (dtype == RIB_DTYPE_BF16)) h->plans.clear();   // kernels are chosen per dtype
   h->compute_bf16 = dtype == RIB_DTYPE_BF16;
   return RIB_OK;
 }
@@ -1401,7 +1433,7 @@ int rib_variant_info(int idx, int geom[10]) {
   const Variant& v = kVariants[idx];
   const int g[10] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0};
   for (int i = 0; i < 10; ++i) geom[i] = g[i];
-  return RIB_OK;
+  return v.BF16 ? 1 : RIB_OK;   // 1: the bf16 matrix-core twin of that geometry
 }
 
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit) {

@@ -165,7 +165,7 @@ class Generator:
                 from . import tuning
                 if self._tuning is None:
                     self._tuning = tuning.load()
-                tuning.apply(self._lib, self._h, self._tuning, B, H, W)
+                tuning.apply(self._lib, self._h, self._tuning, B, H, W, bf16=(self.compute_dtype == "bf16"))
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (B, H, W)):
                 # a stale tuning entry must never break the path: drop it and use the cost model

@@ -23,16 +23,18 @@ def save(table, path=TUNING_PATH):
         json.dump(table, f, indent=0, sort_keys=True)
 
 
-def apply(lib, handle, table, B, H, W):
-    """Pin the tuned choices of shape (B,H,W) on a handle; returns how many were applied."""
+def apply(lib, handle, table, B, H, W, bf16=False):
+    """Pin the tuned choices of shape (B,H,W) on a handle; returns how many were applied.  The table
+    is measured in fp32; a bf16 handle takes the bf16 twin of each tuned geometry where one exists."""
     entry = table.get("%d,%d,%d" % (B, H, W))
     if not entry:
         return 0
     g10 = (C.c_int * 10)()
     geoms = {}
     for i in range(lib.rib_num_variants()):
-        lib.rib_variant_info(i, g10)
-        geoms[tuple(g10)] = i
+        is_bf16 = lib.rib_variant_info(i, g10) == 1
+        if is_bf16 == bool(bf16) or (bf16 and tuple(g10) not in geoms):
+            geoms[tuple(g10)] = i
     n = 0
     for op, choice in entry.items():
         idx = geoms.get(tuple(choice[:10]))

@@ -39,8 +39,8 @@ def main():
     geoms = []
     g10 = (C.c_int * 10)()
     for i in range(nvar):
-        lib.rib_variant_info(i, g10)
-        geoms.append(list(g10))
+        is_bf16 = lib.rib_variant_info(i, g10) == 1
+        geoms.append(list(g10) if not is_bf16 else None)      # the table is measured on the fp32 kernels
     table = tuning.load(args.out)
     report = []
     for size in args.size:
@@ -76,6 +76,8 @@ def main():
             best = (base, None, None)
             results = []
             for vi, g in enumerate(geoms):
+                if g is None:
+                    continue
                 if kclass == 0 and g[9]:
                     continue            # SPADE-epilogue variants only serve SPADE ops
                 # a SPADE op may also run unfused: plain 1x1 variant (+ split-K) and a modulate kernel
