@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
 // ---------------------------------------------------------------------------------------------
 // k_pack: concatenate up to 3 NCHW sources along channels into one zero-padded NHWC tensor
 // (torch.cat at PGNR/models/generator.py:197,232 and the NCHW->NHWC boundary conversion).
-// thread = pixel; grid (ceil(HW/256), B).
+// 64 pixels per 256-thread block; grid (ceil(HW/64), B); dC <= 32.
 // ---------------------------------------------------------------------------------------------
 struct PackParams {
   const float* s0; const float* s1; const float* s2;
@@ -847,22 +847,30 @@ struct PackParams {
 };
 
 __global__ __launch_bounds__(256) void k_pack(const PackParams p) {
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  // 64 pixels per block.  Phase 1: thread = (pixel, channel slice) reads NCHW coalesced along the
+  // pixels; phase 2, after an LDS transpose: consecutive lanes write consecutive 16 bytes of NHWC.
+  __shared__ float tile[64][33];
   const int n = blockIdx.y;
-  if (pix >= p.HW) return;
-  float* d = p.dst + ((size_t)n * p.HW + pix) * p.dC;
-  for (int g = 0; g < p.dC / 4; ++g) {
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = g * 4 + e;
-      float t = 0.f;
+  const int pix0 = blockIdx.x * 64;
+  const int lp = threadIdx.x & 63, slice = threadIdx.x >> 6;        // 4 channel slices
+  const int ctot = p.c0 + p.c1 + p.c2;
+  const int pix = pix0 + lp;
+  for (int j = slice; j < p.dC; j += 4) {
+    float t = 0.f;
+    if (pix < p.HW && j < ctot) {
       if (j < p.c0) t = p.s0[((size_t)n * p.c0 + j) * p.HW + pix];
       else if (j < p.c0 + p.c1) t = p.s1[((size_t)n * p.c1 + (j - p.c0)) * p.HW + pix];
-      else if (j < p.c0 + p.c1 + p.c2) t = p.s2[((size_t)n * p.c2 + (j - p.c0 - p.c1)) * p.HW + pix];
-      v[e] = t;
+      else t = p.s2[((size_t)n * p.c2 + (j - p.c0 - p.c1)) * p.HW + pix];
     }
-    *reinterpret_cast<float4*>(d + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    tile[lp][j] = t;
+  }
+  __syncthreads();
+  const int c4n = p.dC / 4;
+  for (int idx = threadIdx.x; idx < 64 * c4n; idx += 256) {
+    const int q = idx / c4n, g = idx % c4n;
+    if (pix0 + q < p.HW)
+      *reinterpret_cast<float4*>(p.dst + ((size_t)n * p.HW + pix0 + q) * p.dC + g * 4) =
+          make_float4(tile[q][g * 4], tile[q][g * 4 + 1], tile[q][g * 4 + 2], tile[q][g * 4 + 3]);
   }
 }
 

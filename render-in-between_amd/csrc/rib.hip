@@ -771,9 +771,10 @@ struct Builder {
       op.kp.c0 = c0; op.kp.c1 = c1; op.kp.c2 = 0; op.kp.dC = dst.Cp; op.kp.HW = H * W;
       op.k_s0 = US(s0); if (c1) op.k_s1 = US(s1);
       op.k_dst = WS(dst.off);
-      op.grid = dim3((H * W + 255) / 256, B, 1);
+      op.grid = dim3((H * W + 63) / 64, B, 1);
       push(op);
     };
+    if (L.Cp > 32 || Ein.Cp > 32 || I9.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }
     pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
     const int ev_label = record_after_last();   // also the fork point of the side streams
     pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232

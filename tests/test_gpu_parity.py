@@ -271,3 +271,22 @@ def test_bf16_matrix_core_mode_error_is_bounded():
     G32 = rib.Generator(cfg).eval(); G32.load_state_dict(sd)
     i32, m32 = G32(label, None, fake, prev)
     assert float((i32.cpu() - oimg).abs().max()) <= TOL
+
+
+def test_long_autoregressive_chain_stays_within_tolerance():
+    """Error accumulation over a 12-step device-side chain (prev <- fused frame) vs the CPU oracle's
+    frame-by-frame loop: the 1e-3 fp32 bar must hold at the END of the chain, not only per frame."""
+    from oracle import generator_ref
+    spec, sd, G = build("full", 0)
+    H = W = 64
+    T = 12
+    key = synth.smooth_image(spec, 1, H, W, 300)
+    labels = torch.stack([synth.make_inputs(spec, 1, H, W, 300 + t)[0] for t in range(T)])
+    dains = torch.stack([synth.smooth_image(spec, 1, H, W, 400 + t) for t in range(T)])
+    _, _, fuses = G.chain(key, labels, dains, want_all=False)
+    _, _, ofuses = generator_ref.autoregressive_segment(oracle(spec, sd), key, list(labels), list(dains))
+    d_last = float((fuses[-1].cpu() - ofuses[-1]).abs().max())
+    d_max = max(float((fuses[t].cpu() - ofuses[t]).abs().max()) for t in range(T))
+    with open("gpurun_out/parity_chain12_64.json", "w") as f:
+        json.dump({"steps": T, "max_abs_last_frame": d_last, "max_abs_any_frame": d_max}, f)
+    assert d_max <= NORTH_STAR_TOL, (d_last, d_max)
