@@ -778,7 +778,10 @@ struct Builder {
     pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
     const int ev_label = record_after_last();   // also the fork point of the side streams
     pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
-    cur_stream = ST_EMBED; wait_before_next(ev_label);
+    // RIB_LBL_AT=<i>: (experiment) only the label branch goes to a side stream, forked when the main
+    // chain reaches down_<i>, i.e. next to the small-map layers that cannot fill the chip
+    const int lbl_at = getenv("RIB_LBL_AT") ? atoi(getenv("RIB_LBL_AT")) : -1;
+    if (lbl_at < 0) { cur_stream = ST_EMBED; wait_before_next(ev_label); }
     pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
 
     // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
@@ -808,9 +811,12 @@ struct Builder {
     if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
     Act CAT = act(2 * chm, Hm, Wm);
     Norm ncat = norm(CAT.Cp);
-    cur_stream = ST_LABEL; wait_before_next(ev_label);
-    if (!mask_branch(0, L, CAT, ncat, chm)) return false;
-    const int ev_lbl = record_after_last();
+    int ev_lbl = -1;
+    if (lbl_at < 0) {
+      cur_stream = ST_LABEL; wait_before_next(ev_label);
+      if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+      ev_lbl = record_after_last();
+    }
     cur_stream = ST_MAIN;
 
     // ---- main generator (generator.py:201-228) ----
@@ -825,7 +831,14 @@ struct Builder {
     for (int i = 0; i <= D; ++i) {
       Act out; Norm nout;
       const bool last = (i == D);
-      wait_before_next(ev_cond[std::min(c.emb_down, i)]);
+      if (i == std::min(lbl_at, D) && lbl_at >= 0) {
+        const int ev_fork = record_after_last();
+        cur_stream = ST_LABEL; wait_before_next(ev_fork);
+        if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+        ev_lbl = record_after_last();
+        cur_stream = ST_MAIN;
+      }
+      if (lbl_at < 0) wait_before_next(ev_cond[std::min(c.emb_down, i)]);
       if (!spade_block("down_" + std::to_string(i), x, false, nx, cond[std::min(c.emb_down, i)], &out, last ? &nout : nullptr)) return false;
       if (!last) {   // self.downsample = AvgPool2d(3, 2, 1) (generator.py:127,207-208)
         if (out.Cp % 4 != 0 || 256 % (out.Cp / 4) != 0) { error = "avgpool: unsupported channel count"; return false; }

@@ -290,3 +290,20 @@ def test_long_autoregressive_chain_stays_within_tolerance():
     with open("gpurun_out/parity_chain12_64.json", "w") as f:
         json.dump({"steps": T, "max_abs_last_frame": d_last, "max_abs_any_frame": d_max}, f)
     assert d_max <= NORTH_STAR_TOL, (d_last, d_max)
+
+
+def test_full_1024_against_oracle():
+    """BASELINE configs[4] resolution (1024x1024; one sample of the batch): every pixel vs the CPU
+    oracle.  Guards the large-map index arithmetic and the 1M-element InstanceNorm statistics
+    (fp32 per-tile partials + fp64 finalize, SURVEY §7 'hard parts')."""
+    spec, sd, G = build("full", 0)
+    label, fake, prev = synth.make_inputs(spec, 1, 1024, 1024, 77)
+    img, mask = G(label, None, fake, prev)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    oimg, omask = oracle(spec, sd)(label, None, fake, prev)
+    d_img = float((img.cpu() - oimg).abs().max()); d_mask = float((mask.cpu() - omask).abs().max())
+    with open("gpurun_out/parity_1024.json", "w") as f:
+        json.dump({"max_abs_img": d_img, "max_abs_mask": d_mask, "tolerance": NORTH_STAR_TOL}, f)
+    assert d_img <= TOL and d_mask <= TOL, (d_img, d_mask)
+    G._ws.clear()          # release the 4 GB workspace of this shape
+    torch.cuda.empty_cache()
