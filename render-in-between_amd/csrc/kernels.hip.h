@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
 //   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
 //   scale = rstd*gamma, shift = beta - mean*scale   (gamma=1, beta=0 when affine is absent)
 // Tiles are summed in a fixed order in fp64: deterministic and free of fp32 cancellation.
-// grid (Cs/32, B), block 1024 = 32 channels x 32 tile slices.
+// grid (Cs/16, B), block 1024 = 16 channels x 64 tile slices.
 // ---------------------------------------------------------------------------------------------
 struct FinalizeParams {
   const float* part;   // [B][tiles][2][Cs]
@@ -568,23 +568,24 @@ struct FinalizeParams {
 };
 
 __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p) {
-  __shared__ double red[2][32][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  // block = 16 channels x 64 tile slices: short dependent-load chains even for 2048 tiles
+  __shared__ double red[2][64][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const int n = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
   if (c < p.Cs) {
     const float* base = p.part + (size_t)n * p.tiles * 2 * p.Cs;
     int t = sl;
-    for (; t + 96 < p.tiles; t += 128) {   // 4 independent loads in flight per accumulator
+    for (; t + 192 < p.tiles; t += 256) {   // 4 independent loads in flight per accumulator
       const float x0 = base[(size_t)t * 2 * p.Cs + c], y0 = base[(size_t)t * 2 * p.Cs + p.Cs + c];
-      const float x1 = base[(size_t)(t + 32) * 2 * p.Cs + c], y1 = base[(size_t)(t + 32) * 2 * p.Cs + p.Cs + c];
-      const float x2 = base[(size_t)(t + 64) * 2 * p.Cs + c], y2 = base[(size_t)(t + 64) * 2 * p.Cs + p.Cs + c];
-      const float x3 = base[(size_t)(t + 96) * 2 * p.Cs + c], y3 = base[(size_t)(t + 96) * 2 * p.Cs + p.Cs + c];
+      const float x1 = base[(size_t)(t + 64) * 2 * p.Cs + c], y1 = base[(size_t)(t + 64) * 2 * p.Cs + p.Cs + c];
+      const float x2 = base[(size_t)(t + 128) * 2 * p.Cs + c], y2 = base[(size_t)(t + 128) * 2 * p.Cs + p.Cs + c];
+      const float x3 = base[(size_t)(t + 192) * 2 * p.Cs + c], y3 = base[(size_t)(t + 192) * 2 * p.Cs + p.Cs + c];
       a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
       a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
     }
-    for (; t < p.tiles; t += 32) {
+    for (; t < p.tiles; t += 64) {
       a1 += (double)base[(size_t)t * 2 * p.Cs + c];
       a2 += (double)base[(size_t)t * 2 * p.Cs + p.Cs + c];
     }
@@ -592,10 +593,17 @@ __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p)
   red[0][sl][cl] = a1;
   red[1][sl][cl] = a2;
   __syncthreads();
-  if (sl == 0 && c < p.C) {
-    double s1 = 0.0, s2 = 0.0;
+  // fixed-shape tree over the 64 slices (a serial walk by one thread costs 128 dependent LDS reads)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+  for (int s = 32; s >= 1; s >>= 1) {
+    if (sl < s) {
+      red[0][sl][cl] += red[0][sl + s][cl];
+      red[1][sl][cl] += red[1][sl + s][cl];
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && c < p.C) {
+    const double s1 = red[0][0][cl], s2 = red[1][0][cl];
     const double mean = s1 * (double)p.inv_count;
     double var = s2 * (double)p.inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
     if (pix < npix) {
       const float* src = p.slab + ((size_t)n * npix + pix) * p.CoutPad + c4 * 4;
       float4 a = *reinterpret_cast<const float4*>(src);
+#pragma unroll 4
       for (int s = 1; s < p.ksplit; ++s) {
         const float4 t = *reinterpret_cast<const float4*>(src + s * sstride);
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
@@ -710,6 +719,7 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
     const float* src = p.slab + ((size_t)n * npix + pix) * p.npad + colg;
     float4 g = *reinterpret_cast<const float4*>(src);
     float4 b = *reinterpret_cast<const float4*>(src + 32);
+#pragma unroll 4
     for (int s = 1; s < p.ksplit; ++s) {
       const float4 g2 = *reinterpret_cast<const float4*>(src + s * sstride);
       const float4 b2 = *reinterpret_cast<const float4*>(src + s * sstride + 32);

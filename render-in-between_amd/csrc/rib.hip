@@ -609,7 +609,7 @@ struct Builder {
       f.f_part = WS(part_off);
       if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
       f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
-      f.grid = dim3(c.coutp / 32, B, 1);
+      f.grid = dim3(c.coutp / 16, B, 1);
       push(f);
     }
     return true;
@@ -858,7 +858,7 @@ struct Builder {
         f.fp.tiles = blocks; f.fp.Cs = out.Cp; f.fp.C = out.Cp; f.fp.ld = np.ld; f.fp.off = 0;
         f.fp.inv_count = 1.0f / ((float)pooled.H * (float)pooled.W); f.fp.eps = 1e-5f;
         f.f_part = WS(part); f.f_scale = WS(np.sc); f.f_shift = WS(np.sh);
-        f.grid = dim3((out.Cp + 31) / 32, B, 1);
+        f.grid = dim3((out.Cp + 15) / 16, B, 1);
         push(f);
         x = pooled; nx = np;
       } else { x = out; nx = nout; }
