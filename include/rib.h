@@ -123,6 +123,31 @@ int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const
 /* uint8 HWC frame = uint8(clip(x*0.5+0.5,0,1)*255), truncating (PGNR/utils/utils.py:129-142). */
 int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img_nchw,
                  uint8_t* out_nhwc, void* hip_stream);
+/* ---- label-map rasterisation --------------------------------------------------
+ * Replaces, per frame, Dataset._generate_skeleton + _generate_pose_map
+ * (PGNR/datasets/HSM_auto_dataset.py:205-251; drawing rules PGNR/utils/keypoint2img.py:36-88,132-147)
+ * as called from the inference pre-load loop (PGNR/models/evaluator.py:221-229,250): writes the
+ * 22-channel label [3-ch limb drawing in [-1,1] | n_maps gaussian joint maps in [0,1]] of T frames
+ * straight into device memory.  The host keeps what is file parsing and scalar work: reading the
+ * OpenPose json, thresholding the joints and fitting one line per limb (interpPoints,
+ * keypoint2img.py:66-88); the pixels are produced here, bit-identical to the reference.
+ *
+ * rib_stroke: one limb of one frame.  n = int(x1 - x0) samples of np.linspace(int(x0), int(x1), n)
+ * (sample k = k*step + start, the last one = stop), each mapped through a*x + b; swap = 1 when the
+ * line was fitted with the roles of x and y exchanged.  n = 0: limb not drawn.
+ * peaks: (x, y) = (int(x), int(y)) of each joint's one-hot, x = -1 when the joint is off.
+ * weights: the radius+1 half of scipy's normalised gaussian kernel (weights[d] = tap +-d).
+ * All four tables are HOST pointers (a few KB per frame; copied into the workspace on `stream`). */
+typedef struct rib_stroke {
+  int32_t n, swap;
+  double start, step, stop, a, b;
+} rib_stroke;
+size_t rib_rasterise_workspace_bytes(rib_handle* h, int T, int H, int W, int n_edges, int n_maps, int radius);
+int rib_rasterise(rib_handle* h, int T, int H, int W,
+                  const rib_stroke* strokes, int n_edges, const uint8_t* colors_rgb, int stroke_halfwidth,
+                  const int32_t* peaks, int n_maps, const double* weights, int radius,
+                  float* labels, void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Extension op named by the north star but absent from the reference: bilinear
  * flow-grid warp, semantics of torch.nn.functional.grid_sample(img, base+flow*2/(size-1),
  * 'bilinear', padding_mode='border', align_corners=True).  flow [B,2,H,W] in pixels (x,y). */

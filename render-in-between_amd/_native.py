@@ -51,6 +51,10 @@ SIGNATURES = {
     "rib_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "rib_quantise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3),
     "rib_warp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "rib_rasterise_workspace_bytes": (C.c_size_t, [C.c_void_p] + [C.c_int] * 6),
+    "rib_rasterise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
     "rib_num_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rib_tap_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

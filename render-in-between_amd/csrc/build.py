@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "rib.hip")
-DEPS = [SRC, os.path.join(HERE, "kernels.hip.h"),
+DEPS = [SRC, os.path.join(HERE, "kernels.hip.h"), os.path.join(HERE, "raster.hip.h"),
         os.path.join(HERE, "..", "..", "include", "rib.h")]
 OUT = os.path.join(HERE, "librib.so")
 

@@ -72,6 +72,8 @@ struct IgemmParams {
   // output
   int Hout, Wout;
   int tilesX, tilesY;
+  int xcd_chunk;         // > 0: tiles/8; block b works on tile (b%8)*xcd_chunk + b/8, so that each XCD's L2
+                         //      (workgroups go round-robin over the 8 XCDs) holds one contiguous band of tiles
   // --- conv epilogue ---
   float* y;              // [B][Hout][Wout][yC], written at channel offset yoff
   int yC, yoff, Cout;    // Cout = valid output channels
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   // blockIdx.z = n * ksplit + split: split-K slices share the tile and write partial slabs
   const int n = blockIdx.z / p.ksplit;
   const int split = blockIdx.z - n * p.ksplit;
-  const int tile = blockIdx.x;
+  const int tile = p.xcd_chunk ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int ty0 = (tile / p.tilesX) * G::TH;
   const int tx0 = (tile % p.tilesX) * G::TW;
   const int n0 = blockIdx.y * G::BN;

@@ -10,6 +10,7 @@
 //     (:493-510);
 //   * the autoregressive segment driver (PGNR/models/evaluator.py:238-262).
 #include "kernels.hip.h"
+#include "raster.hip.h"
 #include "../../include/rib.h"
 
 #include <algorithm>
@@ -462,6 +463,12 @@ const std::vector<float>* tensor_data(rib_handle* h, const std::string& name) {
 // ------------------------------------------------------------------------------------------
 // plan builder
 // ------------------------------------------------------------------------------------------
+// XCD-aware tile order (RIB_NO_XCD=1 disables): needs the tile count to be a multiple of 8
+static int xcd_chunk_of(int tiles) {
+  static const bool off = getenv("RIB_NO_XCD") != nullptr;
+  return (!off && tiles >= 64 && tiles % 8 == 0) ? tiles / 8 : 0;
+}
+
 struct Builder {
   rib_handle* h;
   Plan* P;
@@ -551,7 +558,7 @@ struct Builder {
     p.pro_ld = a.pro ? a.pro->ld : 0; p.pro_lrelu = a.pro_lrelu ? 1 : 0;
     p.CoutPad = c.coutp;
     p.Hout = Hout; p.Wout = Wout;
-    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
+    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
     p.act = a.act; p.ksplit = S;
     op.x = WS(a.in.off);
     if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
@@ -654,7 +661,7 @@ struct Builder {
       memset(&p, 0, sizeof p);
       p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
       p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
-      p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH();
+      p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
       op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
       op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
@@ -679,7 +686,7 @@ struct Builder {
     memset(&p, 0, sizeof p);
     p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
     p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout;
-    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH();
+    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
     p.ksplit = 1;
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
@@ -1312,6 +1319,78 @@ int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, ui
 int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const float* flow, float* out, void* hip_stream) {
   if (!h || !img || !flow || !out) return RIB_ERR_INVALID;
   hipLaunchKernelGGL(k_warp, dim3((H * W + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W);
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+static_assert(sizeof(rib_stroke) == sizeof(RasterStroke) && sizeof(rib_stroke) == 48, "rib_stroke layout");
+
+namespace {
+struct RasterLayout { size_t strokes, colors, peaks, weights, canvas, total; };
+RasterLayout raster_layout(int T, int H, int W, int n_edges, int n_maps, int radius) {
+  RasterLayout L; size_t o = 0;
+  L.strokes = o; o += align256((size_t)T * n_edges * sizeof(rib_stroke));
+  L.colors = o;  o += align256((size_t)n_edges * sizeof(uint32_t));
+  L.peaks = o;   o += align256((size_t)T * n_maps * 2 * sizeof(int32_t));
+  L.weights = o; o += align256((size_t)(radius + 1) * sizeof(double));
+  L.canvas = o;  o += align256((size_t)T * H * W * sizeof(uint32_t));
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+size_t rib_rasterise_workspace_bytes(rib_handle* h, int T, int H, int W, int n_edges, int n_maps, int radius) {
+  if (!h || T < 1 || H < 1 || W < 1 || n_edges < 0 || n_maps < 0 || radius < 0) return 0;
+  return raster_layout(T, H, W, n_edges, n_maps, radius).total;
+}
+
+int rib_rasterise(rib_handle* h, int T, int H, int W, const rib_stroke* strokes, int n_edges,
+                  const uint8_t* colors_rgb, int stroke_halfwidth, const int32_t* peaks, int n_maps,
+                  const double* weights, int radius, float* labels, void* workspace, size_t workspace_bytes,
+                  void* hip_stream) {
+  if (!h) return RIB_ERR_INVALID;
+  if (h->device < 0) return fail(h, RIB_ERR_INVALID, "rib_rasterise: host-only handle");
+  if (T < 1 || H < 1 || W < 1 || !labels || !workspace || (n_edges > 0 && (!strokes || !colors_rgb)) ||
+      (n_maps > 0 && (!peaks || !weights)))
+    return fail(h, RIB_ERR_INVALID, "rib_rasterise: bad argument");
+  if (3 + n_maps != h->g.c.label_nc)
+    return fail(h, RIB_ERR_INVALID, fmt("rib_rasterise: 3 + %d maps != label_nc %d", n_maps, h->g.c.label_nc));
+  if (H > RASTER_MAXPTS || W > RASTER_MAXPTS) return fail(h, RIB_ERR_INVALID, fmt("rib_rasterise: H, W <= %d", RASTER_MAXPTS));
+  if (radius > 127 || stroke_halfwidth < 1 || stroke_halfwidth > 16) return fail(h, RIB_ERR_INVALID, "rib_rasterise: radius <= 127, 1 <= stroke half-width <= 16");
+  for (size_t i = 0; i < (size_t)T * n_edges; ++i)
+    if (strokes[i].n < 0 || strokes[i].n > RASTER_MAXPTS) return fail(h, RIB_ERR_INVALID, fmt("rib_rasterise: stroke %zu has %d samples", i, strokes[i].n));
+  for (size_t i = 0; i < (size_t)T * n_maps; ++i) {
+    const int32_t x = peaks[2 * i], y = peaks[2 * i + 1];
+    if (x >= W || (x >= 0 && (y < 0 || y >= H))) return fail(h, RIB_ERR_INVALID, fmt("rib_rasterise: peak %zu (%d, %d) outside the frame", i, x, y));
+  }
+  const RasterLayout L = raster_layout(T, H, W, n_edges, n_maps, radius);
+  if (workspace_bytes < L.total) return fail(h, RIB_ERR_WORKSPACE, fmt("workspace %zu < required %zu bytes", workspace_bytes, L.total));
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<uint32_t> packed(n_edges);
+  if (n_edges > 0) {
+    for (int e = 0; e < n_edges; ++e)
+      packed[e] = (uint32_t)colors_rgb[3 * e] | ((uint32_t)colors_rgb[3 * e + 1] << 8) | ((uint32_t)colors_rgb[3 * e + 2] << 16);
+    HIP_TRY(h, hipMemcpyAsync(ws + L.strokes, strokes, (size_t)T * n_edges * sizeof(rib_stroke), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(ws + L.colors, packed.data(), n_edges * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  if (n_maps > 0) {
+    HIP_TRY(h, hipMemcpyAsync(ws + L.peaks, peaks, (size_t)T * n_maps * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(ws + L.weights, weights, (size_t)(radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(h, hipStreamSynchronize(st));        // the caller's (pageable) tables may be reused on return; they are KBs
+  if (n_maps > 0) {
+    HeatParams hp;
+    hp.peaks = reinterpret_cast<const int32_t*>(ws + L.peaks); hp.w = reinterpret_cast<const double*>(ws + L.weights);
+    hp.r = radius; hp.label = labels; hp.T = T; hp.H = H; hp.W = W; hp.nmaps = n_maps; hp.label_nc = 3 + n_maps; hp.ch0 = 3;
+    hipLaunchKernelGGL(k_heatmaps, dim3((H * W + 255) / 256, n_maps, T), dim3(256), 0, st, hp);
+  }
+  SkelParams sp;
+  sp.strokes = reinterpret_cast<const RasterStroke*>(ws + L.strokes); sp.colors = reinterpret_cast<const uint32_t*>(ws + L.colors);
+  sp.nedges = n_edges; sp.canvas = reinterpret_cast<uint32_t*>(ws + L.canvas); sp.label = labels;
+  sp.T = T; sp.H = H; sp.W = W; sp.label_nc = 3 + n_maps; sp.bw = stroke_halfwidth;
+  hipLaunchKernelGGL(k_skeleton, dim3(T), dim3(256), 0, st, sp);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }

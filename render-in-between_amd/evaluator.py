@@ -10,7 +10,9 @@ Differences from the reference, none of which change a pixel:
   * a segment (the frames between two key frames) runs as ONE device-side chain
     (rib_chain): `prev` never leaves HBM and there is no per-frame .cpu() sync
     (evaluator.py:260-262 syncs every frame);
-  * the output quantisation runs on the GPU (rib_quantise).
+  * the output quantisation runs on the GPU (rib_quantise);
+  * the label maps of a whole clip are drawn on the GPU in one call (rib_rasterise) instead of
+    per frame with scipy / numpy loops on the host (evaluator.py:221-229).
 """
 from __future__ import annotations
 
@@ -46,12 +48,16 @@ def _list(d, exts):
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=3):
+    def __init__(self, cfg, lanes=3, label_fn=None):
         """lanes: independent segments kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (measured on MI355X at 512x512: 284 -> 363 frames/s with 3 lanes;
-        the frames inside a segment stay strictly sequential)."""
+        the frames inside a segment stay strictly sequential).
+        label_fn(frames, H, W) -> [T, 22, H, W]: rasteriser override for models that only speak the
+        reference's call protocol (the tests pass the CPU oracle); by default the model's GPU
+        rasteriser is used and a model without one is an error (no host fallback)."""
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
+        self.label_fn = label_fn
         self.height = cfg.model_height                      # HSM_auto_dataset.py:55-56
         self.width = cfg.model_width
         self.gauss_sigma = getattr(cfg, "gauss_sigma", 5)
@@ -79,17 +85,23 @@ class Evaluator:
         a = np.asarray(img, dtype=np.float32) / 255.0
         return torch.from_numpy((a - 0.5) / 0.5).permute(2, 0, 1).contiguous(), (w0, h0)
 
-    def load_label(self, json_path, orig_size):
-        """json -> 22-channel label map: 3-ch skeleton image in [-1,1] + 19 heat-maps in [0,1]
-        (evaluator.py:217-229,250).  Keypoints follow the image resize."""
+    def load_pose(self, json_path, orig_size):
+        """json -> (landmarks, conf) in model-size pixels: the keypoints follow the image resize
+        (A.Resize keypoint rule, evaluator.py:24-26,219)."""
         pose = rasterise.read_json_keypoint(json_path)
         sx, sy = self.width / orig_size[0], self.height / orig_size[1]
         lm = [(pose[i, 0] * sx, pose[i, 1] * sy) for i in range(pose.shape[0])]
-        conf = [pose[i, 2] for i in range(pose.shape[0])]
-        sk = rasterise.skeleton_image(lm, conf, self.height, self.width, self.skeleton_thres, self.foot_thres)
-        pm = rasterise.pose_map(lm, conf, self.height, self.width, self.gauss_sigma, self.skeleton_thres)
-        sk_t = torch.from_numpy((sk.astype(np.float32) / 255.0 - 0.5) / 0.5).permute(2, 0, 1)
-        return torch.cat([sk_t, torch.from_numpy(pm)], dim=0).contiguous()
+        return lm, [pose[i, 2] for i in range(pose.shape[0])]
+
+    def make_labels(self, model, frames):
+        """[(landmarks, conf)] -> [T, 22, H, W] label maps: 3-ch skeleton image in [-1,1] + 19
+        heat-maps in [0,1] (evaluator.py:221-229,250)."""
+        if self.label_fn is not None:
+            return self.label_fn(frames, self.height, self.width)
+        if not hasattr(model, "rasterise"):
+            raise RuntimeError("this model has no GPU rasteriser (rib_rasterise); pass Evaluator(label_fn=...)")
+        return rasterise.rasterise_labels(model, frames, self.height, self.width, self.gauss_sigma,
+                                          self.skeleton_thres, self.foot_thres)
 
     # ---- the driver ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -106,19 +118,20 @@ class Evaluator:
             pose_list = _list(os.path.join(pose_dir, sub), ("json",))
             sample_rate = sample_rate_of(len(pose_list), len(image_list))
             seq_len = (len(image_list) - 1) * sample_rate + 1
-            gts, dains, labels = {}, [], []
+            gts, dains, poses = {}, [], []
             for i in range(seq_len):                                   # pre-load (evaluator.py:205-235)
                 dain, osz = self.load_image(dain_list[i])
                 dains.append(dain)
                 if i % sample_rate == 0:
                     gts[i], _ = self.load_image(image_list[i // sample_rate])
-                labels.append(self.load_label(pose_list[i], osz))
+                poses.append(self.load_pose(pose_list[i], osz))
+            labels = self.make_labels(model, poses)                    # one launch for the whole clip
             keys, segs = split_segments(seq_len, sample_rate)
             fuse = {k: gts[k].unsqueeze(0) for k in keys}              # key frames pass through
             lanes = self._lanes(model, len(segs))
             pending = []
             for si, (k, frames) in enumerate(segs):
-                lab = torch.stack([labels[i] for i in frames]).unsqueeze(1)   # [T,1,22,H,W]
+                lab = labels[frames[0]:frames[-1] + 1].unsqueeze(1)            # [T,1,22,H,W]
                 dn = torch.stack([dains[i] for i in frames]).unsqueeze(1)
                 if lanes:                                              # segments are independent
                     g, st = lanes[si % len(lanes)]

@@ -252,6 +252,29 @@ class Generator:
         _native.check(self._h, self._lib.rib_warp(self._h, B, Cc, H, W, _ptr(img), _ptr(flow), _ptr(out), self._stream()))
         return out
 
+    def rasterise(self, strokes, peaks, weights, radius, height, width, colors=None, halfwidth=None):
+        """Label maps of T frames drawn on the GPU (rib_rasterise): strokes [T, E] of
+        rasterise.STROKE_DTYPE, peaks [T, P, 2] int32, weights [radius+1] fp64 (host arrays, see
+        rasterise.py) -> [T, 3+P, H, W] fp32 CUDA tensor."""
+        import numpy as np
+        from . import rasterise as R
+        strokes = np.ascontiguousarray(strokes, R.STROKE_DTYPE)
+        peaks = np.ascontiguousarray(peaks, np.int32)
+        weights = np.ascontiguousarray(weights, np.float64)
+        colors = np.ascontiguousarray(R.POSE_COLORS if colors is None else colors, np.uint8)
+        halfwidth = R.STROKE_HALFWIDTH if halfwidth is None else int(halfwidth)
+        T, E = strokes.shape
+        P = peaks.shape[1]
+        assert peaks.shape == (T, P, 2) and colors.shape == (E, 3) and weights.shape == (radius + 1,)
+        nbytes = self._lib.rib_rasterise_workspace_bytes(self._h, T, height, width, E, P, radius)
+        with torch.cuda.device(self.device):
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            out = torch.empty((T, 3 + P, height, width), dtype=torch.float32, device=self.device)
+            _native.check(self._h, self._lib.rib_rasterise(
+                self._h, T, height, width, strokes.ctypes.data, E, colors.ctypes.data, halfwidth,
+                peaks.ctypes.data, P, weights.ctypes.data, radius, _ptr(out), _ptr(ws), ws.numel(), self._stream()))
+        return out
+
     # ---- introspection / measurement -----------------------------------------------------------
     def read_taps(self, B, H, W):
         """Intermediate activations of the LAST forward at this shape, as NCHW CPU tensors."""

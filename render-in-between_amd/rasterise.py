@@ -1,17 +1,21 @@
-"""Host-side input rasterisation for the inference driver (SURVEY §8 row f-2,
-"next" scope: CPU restatement, to be moved to the GPU in a later round).
+"""Host side of the GPU label rasteriser (device side: csrc/raster.hip.h
+behind rib_rasterise).
 
-Restates, from reading the reference:
-  * read_json_keypoint            PGNR/utils/utils.py:12-60      OpenPose json -> 19x3 joints
-  * _generate_pose_map (test)     PGNR/datasets/HSM_auto_dataset.py:205-236
-        one-hot at (int(y), int(x)) -> scipy gaussian_filter(sigma) -> / max
-  * _generate_skeleton            PGNR/datasets/HSM_auto_dataset.py:238-251 and
-    PGNR/utils/keypoint2img.py:30-173   coloured limb curves (quadratic curve_fit, bw=4)
+What stays on the host is file parsing and per-limb scalar work:
+  * read_json_keypoint   PGNR/utils/utils.py:12-60          OpenPose json -> 19x3 joints
+  * valid_points         PGNR/utils/keypoint2img.py:115-131 thresholds, zero = joint off
+  * stroke_table         keypoint2img.py:66-88,132-147      one fitted line per limb -> rib_stroke
+  * peak_table           PGNR/datasets/HSM_auto_dataset.py:215-231   one-hot positions
+  * gaussian_weights     the kernel scipy.ndimage.gaussian_filter builds (sigma, truncate 4)
+Every pixel is produced on the GPU.  There is no CPU rasteriser in the product: the CPU
+restatement lives in oracle/rasterise_ref.py and only the tests use it.
 
-Parity status: UNPINNED.  The reference's dataset module cannot be imported in
-the build container (cv2 / albumentations / h5py / torchvision are absent and
-it uses np.float, removed from numpy 2), so these functions are checked only
-against their own documented properties (tests/test_driver.py).
+Line fit.  A limb joins two joints, so the reference's curve_fit(linear, ...) has an exact
+answer, the line through them: a = dy/dx, b = y0 - a*x0.  curve_fit reaches it only to ~1e-12,
+which matters in one situation: a sample a*x+b that lands (almost) on an integer, where the
+truncation .astype(int) can go either way.  Those knife-edge limbs (integer-valued joints, in
+practice only synthetic input) are detected and handed to scipy's curve_fit exactly as the
+reference does, so the drawn pixels are identical in every case.
 """
 from __future__ import annotations
 
@@ -19,8 +23,6 @@ import json
 import warnings
 
 import numpy as np
-from scipy import ndimage
-from scipy.optimize import curve_fit
 
 FOOT_IDX = (8, 9, 10, 11, 12, 13, 14, 15, 16)      # keypoint2img.py:121
 
@@ -31,8 +33,14 @@ POSE_COLORS = [[153, 0, 51], [153, 0, 0], [153, 51, 0], [153, 102, 0], [153, 153
                [102, 153, 0], [51, 153, 0], [0, 153, 0], [0, 153, 51], [0, 153, 102],
                [0, 153, 153], [0, 102, 153], [0, 51, 153], [0, 0, 153],
                [208, 208, 0], [0, 208, 0], [0, 208, 208], [0, 0, 208]]
+STROKE_HALFWIDTH = 4                                                     # keypoint2img.py:145 (bw=4)
+
+STROKE_DTYPE = np.dtype([("n", "<i4"), ("swap", "<i4"), ("start", "<f8"), ("step", "<f8"),
+                         ("stop", "<f8"), ("a", "<f8"), ("b", "<f8")])   # == rib_stroke (include/rib.h)
+assert STROKE_DTYPE.itemsize == 48
 
 
+# ---- json ------------------------------------------------------------------------------------
 def _mean_valid(pts, thres=0.0):
     valid = pts[:, 2] > thres
     return pts[valid].mean(axis=0, keepdims=True) if valid.sum() > 5 else np.zeros((1, 3))
@@ -67,82 +75,96 @@ def read_json_keypoint(path):
     return np.concatenate([body, lh, rh], axis=0)
 
 
-def pose_map(landmarks, conf, height, width, sigma=5, thres=0.001):
-    """(19, H, W) float32 heat-maps in [0, 1], test-phase branch of _generate_pose_map."""
-    maps = np.zeros((len(landmarks), height, width), np.float64)
+# ---- per-frame tables ------------------------------------------------------------------------
+def valid_points(landmarks, conf, height, width, thres1=0.001, thres2=0.001):
+    """(P, 2) joint positions, (0, 0) where the joint is off (keypoint2img.py:115-131)."""
+    pts = np.zeros((len(landmarks), 2))
     for i, ((x, y), c) in enumerate(zip(landmarks, conf)):
-        if x >= 0 and y >= 0 and c > thres and x < width and y < height:
-            m = np.zeros((height, width))
-            m[int(y), int(x)] = 1
-            m = ndimage.gaussian_filter(m, sigma=sigma)
-            maps[i] = m / m.max()
-    return maps.astype(np.float32)
+        t = thres2 if i in FOOT_IDX else thres1
+        if x >= 0 and y >= 0 and c > t and x < width and y < height:
+            pts[i] = (x, y)
+    return pts
 
 
-def _quad(x, a, b, c):
-    return a * x ** 2 + b * x + c
+def _knife_edge(vals):
+    """True when truncating `vals` could flip under a ~1e-9 perturbation of the fitted line."""
+    return bool(np.any(np.abs(vals - np.rint(vals)) < 1e-6 * np.maximum(1.0, np.abs(vals))))
 
 
 def _lin(x, a, b):
     return a * x + b
 
 
-def _interp_points(x, y):
-    """keypoint2img.py:66-88."""
-    if abs(x[:-1] - x[1:]).max() < abs(y[:-1] - y[1:]).max():
-        cy, cx = _interp_points(y, x)
-        return (None, None) if cy is None else (cx, cy)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        if len(x) < 3:
-            popt, _ = curve_fit(_lin, x, y, maxfev=10000)
-        else:
-            popt, _ = curve_fit(_quad, x, y)
-            if abs(popt[0]) > 1:
-                return None, None
-    if x[0] > x[-1]:
-        x = np.array(list(reversed(x))); y = np.array(list(reversed(y)))
-    cx = np.linspace(int(x[0]), int(x[-1]), int(x[-1] - x[0]))
-    cy = _lin(cx, *popt) if len(x) < 3 else _quad(cx, *popt)
-    return cx.astype(int), cy.astype(int)
+def _stroke(x, y):
+    """One limb -> (n, swap, start, step, stop, a, b); n = 0 when nothing is drawn (interpPoints,
+    keypoint2img.py:66-88, for two points)."""
+    x = np.asarray(x, np.float64); y = np.asarray(y, np.float64)
+    swap = 0
+    if abs(x[0] - x[1]) < abs(y[0] - y[1]):          # steep limb: fit x = a*y + b instead
+        x, y, swap = y, x, 1
+    fx, fy = x, y                                     # the fit sees the points in their given order
+    if x[0] > x[1]:
+        x, y = x[::-1], y[::-1]
+    n = int(x[1] - x[0])
+    if n <= 0:
+        return (0, swap, 0.0, 0.0, 0.0, 0.0, 0.0)
+    start, stop = int(x[0]), int(x[1])
+    a = (fy[1] - fy[0]) / (fx[1] - fx[0])
+    b = fy[0] - a * fx[0]
+    cx = np.linspace(start, stop, n)
+    if _knife_edge(a * cx + b):
+        from scipy.optimize import curve_fit
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            (a, b), _ = curve_fit(_lin, fx, fy, maxfev=10000)
+    step = (stop - start) / (n - 1) if n > 1 else 0.0     # np.linspace: step = delta / div
+    return (n, swap, float(start), float(step), float(stop), float(a), float(b))
 
 
-def _set_color(im, yy, xx, color):
-    """keypoint2img.py:36-45: paint, averaging with what is already there."""
-    if (im[yy, xx] == 0).all():
-        im[yy, xx] = color
-    else:
-        im[yy, xx] = ((im[yy, xx].astype(float) + np.array(color, dtype=float)) / 2).astype(np.uint8)
-
-
-def _draw_edge(im, x, y, bw, color):
-    """keypoint2img.py:47-64 with draw_end_points=True."""
-    if x is None or not x.size:
-        return
-    h, w = im.shape[:2]
-    for i in range(-bw, bw):
-        for j in range(-bw, bw):
-            _set_color(im, np.clip(y + i, 0, h - 1), np.clip(x + j, 0, w - 1), color)
-    for i in range(-bw * 3, bw * 3):
-        for j in range(-bw * 3, bw * 3):
-            if i * i + j * j < 4 * bw * bw:
-                _set_color(im, np.clip(np.array([y[0], y[-1]]) + i, 0, h - 1),
-                           np.clip(np.array([x[0], x[-1]]) + j, 0, w - 1), color)
-
-
-def skeleton_image(landmarks, conf, height, width, thres1=0.001, thres2=0.001):
-    """(H, W, 3) uint8 limb drawing (_generate_skeleton, test phase: no random drops)."""
-    pts = np.zeros((len(landmarks), 2))
-    for i, ((x, y), c) in enumerate(zip(landmarks, conf)):
-        t = thres2 if i in FOOT_IDX else thres1
-        if x >= 0 and y >= 0 and c > t and x < width and y < height:      # keypoint2img.py:115-131
-            pts[i] = (x, y)
-    img = np.zeros((height, width, 3), np.uint8)
-    for edge, color in zip(POSE_EDGES, POSE_COLORS):
+def stroke_table(pts, edges=POSE_EDGES):
+    """(len(edges),) STROKE_DTYPE array for one frame (connect_keypoints, keypoint2img.py:132-147:
+    a limb is drawn iff neither end has x == 0)."""
+    out = np.zeros(len(edges), STROKE_DTYPE)
+    for e, edge in enumerate(edges):
         if max(edge) >= len(pts):
             continue
         x, y = pts[edge, 0], pts[edge, 1]
-        if 0 not in x:                                                      # keypoint2img.py:143
-            cx, cy = _interp_points(x, y)
-            _draw_edge(img, cx, cy, 4, color)
-    return img
+        if 0 not in x:
+            out[e] = _stroke(x, y)
+    return out
+
+
+def peak_table(landmarks, conf, height, width, thres=0.001):
+    """(P, 2) int32 (x, y) of each joint's one-hot, (-1, -1) when the joint is off
+    (HSM_auto_dataset.py:226-231)."""
+    out = np.full((len(landmarks), 2), -1, np.int32)
+    for i, ((x, y), c) in enumerate(zip(landmarks, conf)):
+        if x >= 0 and y >= 0 and c > thres and x < width and y < height:
+            out[i] = (int(x), int(y))
+    return out
+
+
+def gaussian_weights(sigma, truncate=4.0):
+    """Half of scipy.ndimage's normalised gaussian kernel: w[d] is the weight of taps +-d,
+    radius = int(truncate * sigma + 0.5)."""
+    sigma = float(sigma)
+    radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:], np.float64), radius
+
+
+def frame_tables(landmarks, conf, height, width, thres1=0.001, thres2=0.001):
+    pts = valid_points(landmarks, conf, height, width, thres1, thres2)
+    return stroke_table(pts), peak_table(landmarks, conf, height, width, thres1)
+
+
+def rasterise_labels(gen, frames, height, width, sigma=5, thres1=0.001, thres2=0.001):
+    """frames: list of (landmarks, conf) already scaled to the model size.
+    -> [T, 22, H, W] fp32 CUDA tensor, drawn by the GPU (gen.rasterise -> rib_rasterise)."""
+    tabs = [frame_tables(lm, cf, height, width, thres1, thres2) for lm, cf in frames]
+    strokes = np.stack([t[0] for t in tabs])
+    peaks = np.stack([t[1] for t in tabs])
+    w, radius = gaussian_weights(sigma)
+    return gen.rasterise(strokes, peaks, w, radius, height, width)

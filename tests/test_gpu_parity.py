@@ -207,7 +207,7 @@ def test_driver_on_gpu_matches_oracle_loop(tmp_path):
     from PIL import Image
     from render_in_between_amd import evaluator as ev
     from oracle import generator_ref
-    from tests.test_driver import _write_example
+    from tests.test_driver import _write_example, oracle_labels
     root = str(tmp_path)
     n = _write_example(root, n_key=2, rate=4, H=32, W=48)
     spec, sd, G = build("full", 0)
@@ -223,7 +223,7 @@ def test_driver_on_gpu_matches_oracle_loop(tmp_path):
     prev = prev.unsqueeze(0)
     for i in range(1, 4):
         d, _ = E.load_image(os.path.join(root, "DAIN", "clipA", "f%03d.png" % i))
-        lab = E.load_label(os.path.join(root, "Predict_motion", "clipA", "f%03d_keypoints.json" % i), osz)
+        lab = oracle_labels([E.load_pose(os.path.join(root, "Predict_motion", "clipA", "f%03d_keypoints.json" % i), osz)], 32, 48)[0]
         img, mask = R(lab.unsqueeze(0), None, d.unsqueeze(0), prev)
         prev = generator_ref.blend(img, mask, d.unsqueeze(0))
         want = generator_ref.quantise_uint8(prev).astype(int)
@@ -307,3 +307,69 @@ def test_full_1024_against_oracle():
     assert d_img <= TOL and d_mask <= TOL, (d_img, d_mask)
     G._ws.clear()          # release the 4 GB workspace of this shape
     torch.cuda.empty_cache()
+
+
+# ---- label rasteriser: rib_rasterise, bit-exact -----------------------------
+def _raster(G, frames, H, W):
+    from render_in_between_amd import rasterise
+    return rasterise.rasterise_labels(G, frames, H, W).cpu()
+
+
+def _oracle_raster(frames, H, W):
+    from tests.test_driver import oracle_labels
+    return oracle_labels(frames, H, W)
+
+
+def test_rasteriser_matches_reference_fixtures_bit_for_bit(golden_dir):
+    """GPU label maps == the reference's own _generate_skeleton / _generate_pose_map outputs
+    (tests/golden/raster_*.npz, made by make_golden_raster.py from the reference's functions)."""
+    spec, sd, G = build("full", 0)
+    for n in "abcde":
+        g = np.load(os.path.join(golden_dir, "raster_%s.npz" % n))
+        H, W = [int(v) for v in g["size"]]
+        lm = [tuple(v) for v in g["landmarks"]]
+        got = _raster(G, [(lm, list(g["conf"]))], H, W)[0].numpy()
+        want_sk = ((g["skeleton"].astype(np.float32) / 255.0 - 0.5) / 0.5).transpose(2, 0, 1)
+        assert got.shape == (22, H, W)
+        assert np.array_equal(got[:3], want_sk), n
+        assert np.array_equal(got[3:], g["pose_map"]), n
+
+
+def test_rasteriser_matches_oracle_on_hard_cases():
+    """Batches of frames; joints on the borders (reflecting gaussian, clamped strokes), short limbs
+    (overlapping end discs), integer-valued joints (knife-edge truncations), missing joints."""
+    spec, sd, G = build("full", 0)
+    rng = np.random.default_rng(5)
+    for (H, W, mode) in [(64, 64, "frac"), (96, 160, "int"), (128, 128, "border"), (48, 80, "tiny"), (256, 192, "frac")]:
+        frames = []
+        for t in range(6):
+            if mode == "border":
+                xy = np.stack([rng.choice([0.2, 1.7, W - 1.3, W - 0.4, W / 2], 19) + rng.uniform(0, 0.2, 19),
+                               rng.choice([0.3, 2.2, H - 2.6, H - 0.2, H / 3], 19) + rng.uniform(0, 0.2, 19)], 1)
+            elif mode == "tiny":
+                xy = np.array([W / 2, H / 2]) + rng.uniform(-6, 6, (19, 2))
+            else:
+                xy = np.stack([rng.uniform(0, W, 19), rng.uniform(0, H, 19)], 1)
+            xy = np.round(xy) if mode == "int" else np.round(xy, 3)
+            conf = rng.uniform(0.2, 1, 19)
+            conf[rng.integers(0, 19, 3)] = 0.0
+            frames.append(([tuple(v) for v in xy], list(conf)))
+        got = _raster(G, frames, H, W)
+        want = _oracle_raster(frames, H, W)
+        assert torch.equal(got[:, 3:], want[:, 3:]), (mode, "heat-maps")
+        assert torch.equal(got[:, :3], want[:, :3]), (mode, "skeleton", int((got[:, :3] != want[:, :3]).sum()))
+
+
+def test_rasteriser_rejects_bad_tables():
+    from render_in_between_amd import rasterise, _native
+    spec, sd, G = build("full", 0)
+    w, r = rasterise.gaussian_weights(5)
+    strokes = np.zeros((1, 18), rasterise.STROKE_DTYPE)
+    peaks = np.full((1, 19, 2), -1, np.int32)
+    out = G.rasterise(strokes, peaks, w, r, 32, 48)
+    assert out.shape == (1, 22, 32, 48) and float(out[:, :3].max()) == -1.0 and float(out[:, 3:].abs().max()) == 0.0
+    bad = peaks.copy(); bad[0, 0] = (48, 3)
+    with pytest.raises(_native.RibError):
+        G.rasterise(strokes, bad, w, r, 32, 48)
+    with pytest.raises(_native.RibError):
+        G.rasterise(strokes, peaks[:, :5], w, r, 32, 48)          # 3 + 5 != label_nc

@@ -132,3 +132,20 @@ def test_unsupported_variants_are_rejected():
         with pytest.raises(NotImplementedError):
             rib.GenSpec.from_cfg(rib.hsm_gen_config(**ov))
     assert generator_ref.sample_rate_of(9, 3) == 4 and generator_ref.sample_rate_of(3, 2) == 2
+
+
+def test_oracle_rasteriser_matches_reference_outputs(golden_dir):
+    """oracle/rasterise_ref.py against the outputs of the reference's own functions
+    (tests/golden/make_golden_raster.py): json reader, limb drawing, heat-maps - bit for bit."""
+    from oracle import rasterise_ref as R
+    for n in "abcde":
+        g = np.load(os.path.join(golden_dir, "raster_%s.npz" % n))
+        H, W = [int(v) for v in g["size"]]
+        kp = R.read_json_keypoint(os.path.join(golden_dir, "raster_json", "pose_%s.json" % n))
+        assert np.array_equal(kp, g["keypoints"])
+        w0, h0 = [int(v) for v in g["orig"]]
+        lm = [(kp[i, 0] * (W / w0), kp[i, 1] * (H / h0)) for i in range(19)]
+        assert np.array_equal(np.array(lm), g["landmarks"])
+        conf = list(kp[:, 2])
+        assert np.array_equal(R.skeleton_image(lm, conf, H, W), g["skeleton"]), n
+        assert np.array_equal(R.pose_map(lm, conf, H, W), g["pose_map"]), n
