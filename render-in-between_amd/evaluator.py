@@ -12,11 +12,16 @@ Differences from the reference, none of which change a pixel:
     (evaluator.py:260-262 syncs every frame);
   * the output quantisation runs on the GPU (rib_quantise);
   * the label maps of a whole clip are drawn on the GPU in one call (rib_rasterise) instead of
-    per frame with scipy / numpy loops on the host (evaluator.py:221-229).
+    per frame with scipy / numpy loops on the host (evaluator.py:221-229);
+  * file decode / encode runs on a thread pool and the quantised frames of a clip come back in
+    one pinned device-to-host copy (at hundreds of frames/s the per-frame
+    .cpu() + PNG encode of evaluator.py:260-266 is the wall).
 """
 from __future__ import annotations
 
 import os
+import time
+from concurrent.futures import ThreadPoolExecutor
 from typing import List
 
 import numpy as np
@@ -48,7 +53,7 @@ def _list(d, exts):
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=3, label_fn=None):
+    def __init__(self, cfg, lanes=3, label_fn=None, png_compress_level=None):
         """lanes: independent segments kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (measured on MI355X at 512x512: 284 -> 363 frames/s with 3 lanes;
         the frames inside a segment stay strictly sequential).
@@ -58,6 +63,9 @@ class Evaluator:
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
         self.label_fn = label_fn
+        self.png_compress_level = png_compress_level        # None: PIL's default, as the reference
+        self.io_threads = max(1, min(32, os.cpu_count() or 1))
+        self.timings = {}                                   # seconds per phase of the last evaluate_from_folder
         self.height = cfg.model_height                      # HSM_auto_dataset.py:55-56
         self.width = cfg.model_width
         self.gauss_sigma = getattr(cfg, "gauss_sigma", 5)
@@ -109,6 +117,9 @@ class Evaluator:
         from PIL import Image
         model.eval()
         written: List[str] = []
+        tm = self.timings = {"load": 0.0, "rasterise": 0.0, "generate": 0.0, "save": 0.0, "frames": 0}
+        pool = ThreadPoolExecutor(self.io_threads)
+        on_gpu = hasattr(model, "quantise")
         for sub in [f for f in sorted(os.listdir(pose_dir)) if os.path.isdir(os.path.join(pose_dir, f))]:
             print("Evaluating {} .....".format(sub))
             frames_dir = os.path.join(save_dir, sub)
@@ -118,14 +129,21 @@ class Evaluator:
             pose_list = _list(os.path.join(pose_dir, sub), ("json",))
             sample_rate = sample_rate_of(len(pose_list), len(image_list))
             seq_len = (len(image_list) - 1) * sample_rate + 1
-            gts, dains, poses = {}, [], []
-            for i in range(seq_len):                                   # pre-load (evaluator.py:205-235)
+            t0 = time.perf_counter()
+
+            def load(i):                                               # pre-load (evaluator.py:205-235)
                 dain, osz = self.load_image(dain_list[i])
-                dains.append(dain)
-                if i % sample_rate == 0:
-                    gts[i], _ = self.load_image(image_list[i // sample_rate])
-                poses.append(self.load_pose(pose_list[i], osz))
+                gt = self.load_image(image_list[i // sample_rate])[0] if i % sample_rate == 0 else None
+                return dain, gt, self.load_pose(pose_list[i], osz)
+            loaded = list(pool.map(load, range(seq_len)))
+            dains = [l[0] for l in loaded]
+            gts = {i: l[1] for i, l in enumerate(loaded) if l[1] is not None}
+            poses = [l[2] for l in loaded]
+            t1 = time.perf_counter()
             labels = self.make_labels(model, poses)                    # one launch for the whole clip
+            if labels.is_cuda:
+                torch.cuda.synchronize(labels.device)
+            t2 = time.perf_counter()
             keys, segs = split_segments(seq_len, sample_rate)
             fuse = {k: gts[k].unsqueeze(0) for k in keys}              # key frames pass through
             lanes = self._lanes(model, len(segs))
@@ -151,14 +169,31 @@ class Evaluator:
                     fuse[i] = fz[t]
             for st in pending:
                 st.synchronize()
-            for i in range(seq_len):                                   # evaluator.py:265-266
-                name = os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png"
-                f = fuse[i]
-                if hasattr(model, "quantise") and f.is_cuda:
-                    q = model.quantise(f)[0].cpu().numpy()
+            # ---- frame sink (evaluator.py:265-266): quantise on the GPU, one pinned copy, threaded PNG encode
+            names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
+            gpu_idx = [i for i in range(seq_len) if on_gpu and fuse[i].is_cuda]
+            host_q = {}
+            if gpu_idx:
+                q = model.quantise(torch.cat([fuse[i] for i in gpu_idx]))           # [N,H,W,3] uint8
+                pinned = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                pinned.copy_(q, non_blocking=True)
+                torch.cuda.current_stream(q.device).synchronize()
+                qn = pinned.numpy()
+                host_q = {i: qn[j] for j, i in enumerate(gpu_idx)}
+            t3 = time.perf_counter()
+
+            def save(i):
+                if i in host_q:
+                    q = host_q[i]
                 else:
-                    x = np.transpose(f[0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
+                    x = np.transpose(fuse[i][0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
                     q = (np.clip(x, 0, 1) * 255.0).astype(np.uint8)
-                Image.fromarray(q).save(name)
-                written.append(name)
+                kw = {} if self.png_compress_level is None else {"compress_level": int(self.png_compress_level)}
+                Image.fromarray(q).save(names[i], **kw)
+                return names[i]
+            written += list(pool.map(save, range(seq_len)))
+            t4 = time.perf_counter()
+            tm["load"] += t1 - t0; tm["rasterise"] += t2 - t1; tm["generate"] += t3 - t2; tm["save"] += t4 - t3
+            tm["frames"] += seq_len
+        pool.shutdown()
         return written

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the folder driver (json + PNG in, PNG out) on a synthetic clip.
+
+    python tools/driver_bench.py [--size 512] [--keys 3] [--rate 32] [--lanes 3]
+
+Writes a clip in the reference's directory layout (inputs/ DAIN/ Predict_motion/), runs
+Evaluator.evaluate_from_folder twice (the first run also builds launch plans) and prints the
+phase times of the second: load (decode + json), rasterise (GPU), generate (GPU chains + quantise +
+one D2H copy), save (PNG encode).
+"""
+import argparse, json, os, sys, tempfile, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import render_in_between_amd as rib
+from render_in_between_amd import evaluator as ev, synth
+from tools.raster_bench import person
+
+
+def write_clip(root, n_key, rate, H, W):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    n = (n_key - 1) * rate + 1
+    for d in ("inputs", "DAIN", "Predict_motion"):
+        os.makedirs(os.path.join(root, d, "clip"))
+    spec = rib.GenSpec.from_cfg(rib.hsm_gen_config())
+    def img(seed):
+        a = np.asarray(synth.smooth_image(spec, 1, H, W, seed))[0]
+        return ((a * 0.5 + 0.5).clip(0, 1) * 255).astype(np.uint8).transpose(1, 2, 0)
+    for k in range(n_key):
+        Image.fromarray(img(k)).save(os.path.join(root, "inputs", "clip", "%04d.png" % k))
+    for i in range(n):
+        Image.fromarray(img(100 + i)).save(os.path.join(root, "DAIN", "clip", "f%04d.png" % i))
+        lm, conf = person(rng, H, W)
+        body = np.zeros((25, 3)); idx = list(range(15)) + [19, 22]
+        for j, k in enumerate(idx):
+            body[k] = (lm[j][0], lm[j][1], conf[j])
+        hand = lambda c: [v for _ in range(21) for v in (c[0] + float(rng.normal(0, 3)), c[1] + float(rng.normal(0, 3)), 0.8)]
+        doc = {"people": [{"pose_keypoints_2d": [float(v) for v in body.reshape(-1)],
+                           "hand_left_keypoints_2d": hand(lm[17]), "hand_right_keypoints_2d": hand(lm[18])}]}
+        with open(os.path.join(root, "Predict_motion", "clip", "f%04d_keypoints.json" % i), "w") as f:
+            json.dump(doc, f)
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--keys", type=int, default=3)
+    ap.add_argument("--rate", type=int, default=32)
+    ap.add_argument("--lanes", type=int, default=3)
+    a = ap.parse_args()
+    H = W = a.size
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=H, model_width=W, gauss_sigma=5, skeleton_thres=0.001, foot_thres=0.001)
+    spec = rib.GenSpec.from_cfg(cfg.gen)
+    G = rib.Generator(cfg.gen).eval()
+    G.load_state_dict(synth.make_state_dict(spec, 0, power_iters=3))
+    with tempfile.TemporaryDirectory() as root:
+        n = write_clip(root, a.keys, a.rate, H, W)
+        E = ev.Evaluator(cfg, lanes=a.lanes)
+        dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
+        for rep in range(2):
+            t0 = time.perf_counter()
+            out = E.evaluate_from_folder(G, *dirs, os.path.join(root, "out%d" % rep))
+            wall = time.perf_counter() - t0
+        tm = dict(E.timings)
+    gen = n - a.keys
+    print(json.dumps({"size": a.size, "frames": n, "generated": gen, "lanes": a.lanes, "io_threads": E.io_threads,
+                      "wall_s": wall, "frames_per_s_end_to_end": n / wall,
+                      "phase_s": {k: round(v, 4) for k, v in tm.items() if k != "frames"},
+                      "generate_frames_per_s": gen / tm["generate"]}))
+
+
+if __name__ == "__main__":
+    main()
