@@ -121,7 +121,12 @@ struct IgemmGeom {
   static constexpr int TAPS = KS * KS;
 };
 
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false>
+// AUX / PRO: whether the fused-1x1-shortcut loop and the input prologue are compiled in.  They are
+// run-time options of the generic kernel, but merely carrying their code costs 24 + 15 VGPRs in the
+// main loop (135 -> 89 for the 8x16 / 32-column / 32-channel variant: 3 -> 4 waves per SIMD), so the
+// launcher picks the leanest instantiation that covers a launch (pick_igemm_fn in rib.hip).
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
+          bool AUX = true, bool PRO = true>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS> G;
   constexpr bool N16 = (NF == 0);
@@ -226,12 +231,14 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       int pix, iy, ix;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (slot_inb(i, pix, iy, ix))
-        v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.Win + ix) * p.xC + kc + ac4 * 4);
+        v = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + kc + ac4 * 4));   // < 2^31 elements per sample (checked by the host)
       areg[i] = v;
     }
-    if (p.pro_scale) {
-      psc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + ac4 * 4);
-      psh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * 4);
+    if constexpr (PRO) {
+      if (p.pro_scale) {
+        psc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + ac4 * 4);
+        psh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * 4);
+      }
     }
   };
   // fused prologue on the way into LDS: InstanceNorm affine + LeakyReLU; conv zero padding is
@@ -242,8 +249,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       int pix, iy, ix;
       const bool inb = slot_inb(i, pix, iy, ix);
       float4 v = areg[i];
-      if (!raw && p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
-      if (!raw && p.pro_lrelu) v = lrelu4(v);
+      if constexpr (PRO) {
+        if (!raw && p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
+        if (!raw && p.pro_lrelu) v = lrelu4(v);
+      }
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tid + i * 256 < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
     }
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   }
 
   // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----
-  if (KS == 3 && STRIDE == 1 && !UPS && !SPADE && p.x2 != nullptr && split == p.ksplit - 1) {
+  if constexpr (AUX && KS == 3 && STRIDE == 1 && !UPS && !SPADE) if (p.x2 != nullptr && split == p.ksplit - 1) {
     const float* x2n = p.x2 + (size_t)n * p.Hin * p.Win * p.x2C;
     auto loadB2 = [&](int kc) {
 #pragma unroll
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
         int pix, iy, ix;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot_inb(i, pix, iy, ix))
-          v = *reinterpret_cast<const float4*>(x2n + ((size_t)iy * p.Win + ix) * p.x2C + kc + ac4 * 4);
+          v = *reinterpret_cast<const float4*>(x2n + (unsigned)((iy * p.Win + ix) * p.x2C + kc + ac4 * 4));
         areg[i] = v;
       }
     };

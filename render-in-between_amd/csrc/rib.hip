@@ -148,8 +148,10 @@ std::vector<ConvDef> build_inventory(const Cfg& g) {
 typedef void (*IgemmFn)(const IgemmParams);
 struct Variant {
   int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
-  IgemmFn fn;
+  IgemmFn fn;          // generic instantiation (fused-shortcut loop and input prologue compiled in)
   bool BF16 = false;   // bf16 matrix-core twin of the same geometry
+  IgemmFn fn_pro = nullptr;    // without the fused-shortcut loop
+  IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
@@ -158,10 +160,25 @@ struct Variant {
     return (ih * iw * (BK + 4) + 2 * BN() * (BK + 4)) * 4;
   }
 };
-#define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
+// RIB_V: convolution geometries, three instantiations (generic / no shortcut loop / lean); the
+// shortcut loop only exists for 3x3 stride-1 gathers, elsewhere "generic" already is "pro".
+// RIB_VS: SPADE geometries (one instantiation).  RIB_VB: bf16 twins (generic only).
+#define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP)                                                         \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                             \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, (KS == 3 && S == 1 && !UPS), true>, false,   \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, true>,                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, false>}
+#define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
 #define RIB_VB(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true}
+
+// the leanest instantiation that covers a launch
+inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
+  if (p.x2 != nullptr) return v->fn;
+  if (p.pro_scale == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
+  return v->fn_pro ? v->fn_pro : v->fn;
+}
 
 const Variant kVariants[] = {
     // 3x3 stride 1, tile 8x16 (4 waves along M), BN 32 / 64
@@ -194,10 +211,10 @@ const Variant kVariants[] = {
     RIB_V(8, 1, 4, 1, 1, 32, 1, 1, false, false),  RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, false),
     RIB_V(8, 2, 2, 1, 1, 64, 1, 1, false, false),
     // SPADE: 1x1 gamma/beta GEMM on the condition map + modulate epilogue
-    RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_V(8, 1, 4, 1, 2, 32, 1, 1, false, true),
-    RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_V(8, 2, 2, 1, 2, 64, 1, 1, false, true),
-    RIB_V(16, 4, 1, 1, 4, 32, 1, 1, false, true),  RIB_V(16, 4, 1, 2, 2, 32, 1, 1, false, true),
-    RIB_V(16, 4, 1, 2, 2, 64, 1, 1, false, true),
+    RIB_VS(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_VS(8, 1, 4, 1, 2, 32, 1, 1, false, true),
+    RIB_VS(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_VS(8, 2, 2, 1, 2, 64, 1, 1, false, true),
+    RIB_VS(16, 4, 1, 1, 4, 32, 1, 1, false, true),  RIB_VS(16, 4, 1, 2, 2, 32, 1, 1, false, true),
+    RIB_VS(16, 4, 1, 2, 2, 64, 1, 1, false, true),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
@@ -964,6 +981,14 @@ Plan* get_plan(rib_handle* h, int B, int H, int W) {
     h->err = fmt("unsupported shape B=%d H=%d W=%d: H and W must be positive multiples of %d (SURVEY F5)", B, H, W, mult);
     return nullptr;
   }
+  {  // the kernels address one sample with 32-bit element offsets: H*W*C < 2^31 for every activation
+    const rib_config& c = h->g.c;
+    const size_t widest = (size_t)std::max(std::max(c.emb_filters, c.mask_filters * 2), std::max(c.num_filters * 2, 32));
+    if ((size_t)H * W * widest >= (1ull << 31)) {
+      h->err = fmt("unsupported shape H=%d W=%d: a full-resolution activation exceeds 2^31 elements", H, W);
+      return nullptr;
+    }
+  }
   std::unique_ptr<Plan> P(new Plan());
   P->B = B; P->H = H; P->W = W;
   Builder b; b.h = h; b.P = P.get(); b.B = B;
@@ -1016,7 +1041,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
-        hipLaunchKernelGGL(op.var->fn, op.grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(pick_igemm_fn(op.var, p), op.grid, dim3(256), 0, st, p);
       } break;
       case OP_FINALIZE: {
         FinalizeParams p = op.fp;
