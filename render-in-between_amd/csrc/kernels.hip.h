@@ -19,6 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RIB_EXP
+#define RIB_EXP 0   // elimination switches for tools/probes/igemm_harness.hip; 0 in the product build
+#endif
+
 namespace rib {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -102,8 +106,9 @@ struct IgemmParams {
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
 // WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS>
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1>
 struct IgemmGeom {
+  static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
   static constexpr int TH = FRH * MF * WM;
   static constexpr int TW = FRW;
@@ -115,9 +120,11 @@ struct IgemmGeom {
   static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
   static constexpr int SA = IH * IW * CK;      // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
-  static constexpr int NB4 = (BN * BK / 4 + 255) / 256;   // float4 filter loads per thread per tap
+  static constexpr int NB4 = (BN * BK / 4 + NT - 1) / NT; // float4 filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
-  static constexpr int SMEM = SA + 2 * SB > SRED ? SA + 2 * SB : SRED;
+  static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
+  static constexpr int SMEM0 = SA + 2 * SB > SRED ? SA + 2 * SB : SRED;
+  static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
   static constexpr int TAPS = KS * KS;
 };
 
@@ -125,24 +132,31 @@ struct IgemmGeom {
 // run-time options of the generic kernel, but merely carrying their code costs 24 + 15 VGPRs in the
 // main loop (135 -> 89 for the 8x16 / 32-column / 32-channel variant: 3 -> 4 waves per SIMD), so the
 // launcher picks the leanest instantiation that covers a launch (pick_igemm_fn in rib.hip).
+// KW > 1: in-workgroup split-K.  KW groups of 4 waves (256*KW threads) work on the SAME tile: they share
+// the staged input tile and filter slices, each group runs 1/KW of every tap's channel steps, and the
+// partial accumulators are summed through LDS before the epilogue.  Gives an under-filled launch KW x
+// the wavefronts without the slab round trip and the second launch of grid-level split-K.
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
-          bool AUX = true, bool PRO = true>
-__global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
-  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS> G;
+          bool AUX = true, bool PRO = true, int KW = 1>
+__global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW> G;
+  constexpr int NT = G::NT;
+  static_assert(KW == 1 || (!BF16 && NF > 0 && !SPADE && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column conv path, BK/8 divisible by KW");
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
   static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0), "16-column path: 8x16-style tiles only");
   static_assert(!UPS || (STRIDE == 1 && KS == 3), "upsample gather only for 3x3 stride 1");
-  static_assert(256 % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
+  static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   float* sA = smem;
   float* sB = smem + G::SA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int kw = KW == 1 ? 0 : (tid >> 8);      // wave group (in-workgroup K slice)
+  const int wave = (tid >> 6) & 3;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -169,6 +183,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   for (int mf = 0; mf < MF; ++mf) fy[mf] = (wm * MF + mf) * G::FRH + li / FRW;
 
   f32x16 acc[MF][NFE];
+  // experiment (RIB_EXP bit 2): two interleaved accumulation chains for single-fragment waves
+  constexpr bool DUAL = (RIB_EXP & 4) && !BF16 && !N16 && MF * NFE == 1;
+  f32x16 accb;
+  if (DUAL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  }
   f32x4 acc16[MF][2];     // 16-column path: two 16-pixel sub-fragments (tile rows) per 32-pixel block
   if (!N16) {
 #pragma unroll
@@ -195,18 +216,19 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   auto loadB = [&](int kc, int tap) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / (BK / 4), c4 = idx % (BK / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < G::BN && n0 + row < p.CoutPad)
-        v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * 4);
+        v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
+                          : *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * 4);
       breg[i] = v;
     }
   };
   auto storeB = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx / (BK / 4), c4 = idx % (BK / 4);
       if (row < G::BN)
         *reinterpret_cast<float4*>(sB + buf * G::SB + row * G::CK + c4 * 4) = breg[i];
@@ -214,12 +236,12 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   };
 
   constexpr int total4 = G::IH * G::IW * (BK / 4);
-  constexpr int NA4 = (total4 + 255) / 256;
+  constexpr int NA4 = (total4 + NT - 1) / NT;
   const int ac4 = tid % (BK / 4);           // this thread's channel group, the same in every slot
   float4 areg[NA4];
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
   auto slot_inb = [&](int i, int& pix, int& iy, int& ix) -> bool {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     pix = idx / (BK / 4);
     const int ly = pix / G::IW, lx = pix % G::IW;
     iy = iy0 + ly; ix = ix0 + lx;
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
         if (!raw && p.pro_lrelu) v = lrelu4(v);
       }
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid + i * 256 < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
+      if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
     }
   };
 
@@ -325,22 +347,31 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
         return;
       }
     }
+    constexpr int KBW = BK / 8 / KW;          // 8-channel steps of one wave group
 #pragma unroll
-    for (int kb = 0; kb < BK / 8; ++kb) {
+    for (int kj = 0; kj < KBW; ++kj) {
+      const int kb = kw * KBW + kj;
       float4 a[MF], b[NFE];
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + lh * 4 + kb * 8);
 #pragma unroll
       for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
+      if constexpr (DUAL) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc[0][0], 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, accb, 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc[0][0], 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, accb, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NFE; ++nf) {
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
-        }
+          for (int nf = 0; nf < NFE; ++nf) {
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
+          }
+      }
     }
   };
 
@@ -348,7 +379,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
   prefetchA(kc_begin);
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
     __syncthreads();   // every wave is done reading sA / sB of the previous chunk
-    writeA(false);
+    if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
 #pragma unroll 1
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int buf = tap & 1;
@@ -360,7 +391,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       }
       // next input chunk: issued AFTER the filter load so that the in-order vmcnt wait at the
       // next storeB does not have to cover it
-      if (tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+      if (!(RIB_EXP & 2) && tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
       __syncthreads();
       compute_tap(tap / KS, tap % KS, buf);
     }
@@ -372,7 +403,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
     auto loadB2 = [&](int kc) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
@@ -400,6 +431,39 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p) {
       __syncthreads();
       compute_tap(1, 1, 0);
     }
+  }
+
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += accb[r];
+  }
+
+  if constexpr (KW > 1) {
+    // sum the wave groups' partial accumulators through LDS, one group per round (16 KB per fragment);
+    // groups 1.. are done afterwards (finished waves do not take part in later barriers)
+    float* rb = smem + (size_t)wave * (MF * NFE * 16 * 64) + lane;
+#pragma unroll 1
+    for (int g = 1; g < KW; ++g) {
+      __syncthreads();
+      if (kw == g) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NFE; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rb[((mf * NFE + nf) * 16 + r) * 64] = acc[mf][nf][r];
+      }
+      __syncthreads();
+      if (kw == 0) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NFE; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] += rb[((mf * NFE + nf) * 16 + r) * 64];
+      }
+    }
+    if (kw != 0) return;
   }
 
   // ------------------------------------ epilogue ------------------------------------

@@ -1,5 +1,5 @@
 """Measured kernel choices (tools/autotune.py) for gfx950: per (B,H,W) and per
-launch, the tile geometry {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE} and split-K
+launch, the tile geometry {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE}, split-K (and wave groups KW)
 factor that ran fastest on an MI355X.  Shapes without an entry fall back to the
 analytic cost model in csrc/rib.hip (choose_variant)."""
 from __future__ import annotations
@@ -29,15 +29,19 @@ def apply(lib, handle, table, B, H, W, bf16=False):
     entry = table.get("%d,%d,%d" % (B, H, W))
     if not entry:
         return 0
-    g10 = (C.c_int * 10)()
+    g11 = (C.c_int * 11)()
     geoms = {}
     for i in range(lib.rib_num_variants()):
-        is_bf16 = lib.rib_variant_info(i, g10) == 1
-        if is_bf16 == bool(bf16) or (bf16 and tuple(g10) not in geoms):
-            geoms[tuple(g10)] = i
+        is_bf16 = lib.rib_variant_info(i, g11) == 1
+        if is_bf16 == bool(bf16) or (bf16 and tuple(g11) not in geoms):
+            geoms[tuple(g11)] = i
     n = 0
     for op, choice in entry.items():
-        idx = geoms.get(tuple(choice[:10]))
+        # entry = geometry[10] + [ksplit] (+ [KW], wave groups per workgroup; 1 when absent)
+        kwg = int(choice[11]) if len(choice) > 11 else 1
+        idx = geoms.get(tuple(choice[:10]) + (kwg,))
+        if idx is None and bf16:
+            idx = geoms.get(tuple(choice[:10]) + (1,))
         if idx is None:
             continue                      # variant table changed since tuning: model choice
         if lib.rib_set_choice(handle, B, H, W, op.encode(), idx, int(choice[10])) == 0:
