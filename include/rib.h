@@ -176,10 +176,10 @@ int rib_num_launches(rib_handle* h, int B, int H, int W);
 
 /* ---- tuning hooks (tools/autotune.py): the launch plan picks, per convolution, one of a small set
  * of tile geometries and a split-K factor from an analytic cost model; a measured choice can be
- * pinned per (B,H,W, op name).  geom = {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE,KW} (KW: wave
- * groups per workgroup, in-workgroup split-K). ---- */
+ * pinned per (B,H,W, op name).  geom = {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE,KW,TB} (KW: wave
+ * groups per workgroup, in-workgroup split-K; TB: filter slices staged per barrier). ---- */
 int rib_num_variants(void);
-int rib_variant_info(int idx, int geom[11]);   /* returns 1 for a bf16 matrix-core twin, 0 for fp32, <0 on error */
+int rib_variant_info(int idx, int geom[12]);   /* returns 1 for a bf16 matrix-core twin, 0 for fp32, <0 on error */
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit);
 int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label,
                 const float* img_fake, const float* img_prev, float* img, float* mask, void* workspace,

@@ -106,7 +106,7 @@ struct IgemmParams {
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
 // WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1>
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1>
 struct IgemmGeom {
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
@@ -123,7 +123,7 @@ struct IgemmGeom {
   static constexpr int NB4 = (BN * BK / 4 + NT - 1) / NT; // float4 filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
-  static constexpr int SMEM0 = SA + 2 * SB > SRED ? SA + 2 * SB : SRED;
+  static constexpr int SMEM0 = SA + 2 * TB * SB > SRED ? SA + 2 * TB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
   static constexpr int TAPS = KS * KS;
 };
@@ -132,14 +132,17 @@ struct IgemmGeom {
 // run-time options of the generic kernel, but merely carrying their code costs 24 + 15 VGPRs in the
 // main loop (135 -> 89 for the 8x16 / 32-column / 32-channel variant: 3 -> 4 waves per SIMD), so the
 // launcher picks the leanest instantiation that covers a launch (pick_igemm_fn in rib.hip).
+// TB = 3: the three filter slices of one filter row are staged per barrier (3 barriers per chunk instead
+// of 9, +4 slices of LDS): pays on launches that leave LDS to spare (<= 2 workgroups per CU).
 // KW > 1: in-workgroup split-K.  KW groups of 4 waves (256*KW threads) work on the SAME tile: they share
 // the staged input tile and filter slices, each group runs 1/KW of every tap's channel steps, and the
 // partial accumulators are summed through LDS before the epilogue.  Gives an under-filled launch KW x
 // the wavefronts without the slab round trip and the second launch of grid-level split-K.
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
-          bool AUX = true, bool PRO = true, int KW = 1>
+          bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
-  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW> G;
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB> G;
+  static_assert(TB == 1 || (TB == 3 && KS == 3), "filter slices per barrier: one tap, or one row of a 3x3 filter");
   constexpr int NT = G::NT;
   static_assert(KW == 1 || (!BF16 && NF > 0 && !SPADE && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column conv path, BK/8 divisible by KW");
   constexpr bool N16 = (NF == 0);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 
   // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
   // filter slice / input chunk are in flight while the current one feeds the matrix cores ----
-  float4 breg[G::NB4];
+  float4 breg[G::NB4 * TB];
   auto loadB = [&](int kc, int tap) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
@@ -233,6 +236,31 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       if (row < G::BN)
         *reinterpret_cast<float4*>(sB + buf * G::SB + row * G::CK + c4 * 4) = breg[i];
     }
+  };
+
+  auto loadB3 = [&](int kc, int dy) {     // TB == 3: the three slices of filter row dy
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < G::NB4; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < G::BN && n0 + row < p.CoutPad)
+          v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + (dy * 3 + t) * p.Cin + kc + c4 * 4);
+        breg[(TB == 3 ? t : 0) * G::NB4 + i] = v;
+      }
+  };
+  auto storeB3 = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < G::NB4; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        if (row < G::BN)
+          *reinterpret_cast<float4*>(sB + (buf * 3 + t) * G::SB + row * G::CK + c4 * 4) = breg[(TB == 3 ? t : 0) * G::NB4 + i];
+      }
   };
 
   constexpr int total4 = G::IH * G::IW * (BK / 4);
@@ -375,6 +403,30 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     }
   };
 
+  if constexpr (TB == 3) {
+    loadB3(kc_begin, 0);
+    prefetchA(kc_begin);
+    int stage = 0;
+    for (int kc = kc_begin; kc < kc_end; kc += BK) {
+      __syncthreads();
+      writeA(false);
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy, ++stage) {
+        const int buf = stage & 1;
+        storeB3(buf);
+        {
+          int ndy = dy + 1, nkc = kc;
+          if (ndy == 3) { ndy = 0; nkc = kc + BK; }
+          if (nkc < kc_end) loadB3(nkc, ndy);
+        }
+        if (dy == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+        __syncthreads();
+        compute_tap(dy, 0, buf * 3 + 0);
+        compute_tap(dy, 1, buf * 3 + 1);
+        compute_tap(dy, 2, buf * 3 + 2);
+      }
+    }
+  } else {
   loadB(kc_begin, 0);
   prefetchA(kc_begin);
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
@@ -395,6 +447,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       __syncthreads();
       compute_tap(tap / KS, tap % KS, buf);
     }
+  }
   }
 
   // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----

@@ -153,12 +153,13 @@ struct Variant {
   IgemmFn fn_pro = nullptr;    // without the fused-shortcut loop
   IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int KW = 1;                  // in-workgroup split-K: KW groups of 4 waves (256*KW threads) per tile
+  int TB = 1;                  // filter slices staged per barrier: 1 tap, or 3 = one row of a 3x3 filter
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
     const int ih = UPS ? TH() / 2 + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() / 2 + 2 : (TW() - 1) * STRIDE + KS;
-    const int main_loop = (ih * iw * (BK + 4) + 2 * BN() * (BK + 4)) * 4;
+    const int main_loop = (ih * iw * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
   }
@@ -177,6 +178,12 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, (KS == 3 && S == 1 && !UPS), true, KW>, false,      \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, true, KW>,                                  \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, false, KW>, KW}
+// RIB_VT: three-taps-per-barrier twin of a 3x3 convolution geometry
+#define RIB_VT(FRW, WM, WN, MF, NF, BK, S, UPS)                                                                         \
+  Variant{FRW, WM, WN, MF, NF, BK, S, 3, UPS, false,                                                                    \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, (S == 1 && !UPS), true, 1, 3>, false,               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, true, 1, 3>,                                \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3>, 1, 3}
 #define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
 #define RIB_VB(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
@@ -234,6 +241,11 @@ const Variant kVariants[] = {
     RIB_VK(16, 4, 1, 1, 1, 32, 1, 3, true, 2),  RIB_VK(16, 4, 1, 2, 1, 32, 1, 3, true, 2),
     RIB_VK(16, 4, 1, 1, 1, 32, 1, 1, false, 2), RIB_VK(16, 4, 1, 1, 2, 32, 1, 1, false, 2),
     RIB_VK(16, 4, 1, 1, 2, 64, 1, 1, false, 2), RIB_VK(8, 2, 2, 1, 1, 64, 1, 1, false, 2),
+    // ---- three-taps-per-barrier twins for launches with LDS to spare (<= 2 workgroups per CU) ----
+    RIB_VT(16, 4, 1, 1, 1, 32, 1, false), RIB_VT(16, 4, 1, 1, 2, 32, 1, false), RIB_VT(16, 4, 1, 2, 1, 32, 1, false),
+    RIB_VT(8, 2, 2, 1, 1, 32, 1, false),  RIB_VT(16, 4, 1, 1, 1, 16, 1, false), RIB_VT(16, 4, 1, 1, 2, 16, 1, false),
+    RIB_VT(8, 2, 2, 1, 1, 32, 2, false),  RIB_VT(8, 2, 2, 1, 1, 16, 2, false),  RIB_VT(16, 4, 1, 1, 2, 16, 2, false),
+    RIB_VT(16, 4, 1, 1, 1, 32, 1, true),  RIB_VT(16, 4, 1, 2, 1, 32, 1, true),  RIB_VT(16, 4, 1, 1, 2, 32, 1, true),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
@@ -281,7 +293,7 @@ Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, in
     if (v.BF16 != bf16) continue;
     const int BK = v.BK;
     // in-workgroup split-K only where the tile grid alone cannot fill the chip
-    if (v.KW > 1 && (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW()) * ((ncols + v.BN() - 1) / v.BN()) * B >= 512) continue;
+    if ((v.KW > 1 || v.TB > 1) && (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW()) * ((ncols + v.BN() - 1) / v.BN()) * B >= 512) continue;
     const int nchunks = Cin / BK;
     const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
     const long ntiles = v.NF == 0 ? 1 : (ncols + v.BN() - 1) / v.BN();
@@ -298,7 +310,7 @@ Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, in
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
       // in-workgroup split-K: KW wave groups interleave on the same SIMDs, which hides 1/KW more of the
       // overheads; the accumulator hand-over costs two barriers and 16 KB of LDS traffic per extra group
-      const double ovh_wg = (chunks * (taps * 350.0 + 600.0) + 7000.0) / v.KW + (v.KW - 1) * 1500.0;
+      const double ovh_wg = (chunks * (taps / v.TB * 350.0 + 600.0) + 7000.0) / v.KW + (v.KW - 1) * 1500.0;
       const double mfma_wg = (double)chunks * taps * mfma_tap;
       const double t_lat = std::ceil((double)wgs / (256.0 * occ)) * (mfma_wg + ovh_wg);
       const double t_cu = std::ceil((double)wgs / 256.0) * (mfma_wg + ovh_wg / occ);
@@ -1558,8 +1570,8 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
   const Op& op = P->ops[idx];
   if (op.kind == OP_IGEMM)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.flops);
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB, op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;
@@ -1569,11 +1581,11 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
 // shape, and time a single op of the plan in isolation ----
 int rib_num_variants(void) { return kNumVariants; }
 
-int rib_variant_info(int idx, int geom[11]) {
+int rib_variant_info(int idx, int geom[12]) {
   if (idx < 0 || idx >= kNumVariants || !geom) return RIB_ERR_INVALID;
   const Variant& v = kVariants[idx];
-  const int g[11] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW};
-  for (int i = 0; i < 11; ++i) geom[i] = g[i];
+  const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.TB};
+  for (int i = 0; i < 12; ++i) geom[i] = g[i];
   return v.BF16 ? 1 : RIB_OK;   // 1: the bf16 matrix-core twin of that geometry
 }
 

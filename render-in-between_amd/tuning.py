@@ -29,7 +29,7 @@ def apply(lib, handle, table, B, H, W, bf16=False):
     entry = table.get("%d,%d,%d" % (B, H, W))
     if not entry:
         return 0
-    g11 = (C.c_int * 11)()
+    g11 = (C.c_int * 12)()
     geoms = {}
     for i in range(lib.rib_num_variants()):
         is_bf16 = lib.rib_variant_info(i, g11) == 1
@@ -37,11 +37,13 @@ def apply(lib, handle, table, B, H, W, bf16=False):
             geoms[tuple(g11)] = i
     n = 0
     for op, choice in entry.items():
-        # entry = geometry[10] + [ksplit] (+ [KW], wave groups per workgroup; 1 when absent)
+        # entry = geometry[10] + [ksplit] (+ [KW, TB]: wave groups per workgroup, filter slices per
+        # barrier; 1 when absent)
         kwg = int(choice[11]) if len(choice) > 11 else 1
-        idx = geoms.get(tuple(choice[:10]) + (kwg,))
+        tb = int(choice[12]) if len(choice) > 12 else 1
+        idx = geoms.get(tuple(choice[:10]) + (kwg, tb))
         if idx is None and bf16:
-            idx = geoms.get(tuple(choice[:10]) + (1,))
+            idx = geoms.get(tuple(choice[:10]) + (1, 1))
         if idx is None:
             continue                      # variant table changed since tuning: model choice
         if lib.rib_set_choice(handle, B, H, W, op.encode(), idx, int(choice[10])) == 0:

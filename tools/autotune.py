@@ -37,7 +37,7 @@ def main():
     h = G._h
     nvar = lib.rib_num_variants()
     geoms = []
-    g10 = (C.c_int * 11)()
+    g10 = (C.c_int * 12)()
     for i in range(nvar):
         is_bf16 = lib.rib_variant_info(i, g10) == 1
         geoms.append(list(g10) if not is_bf16 else None)      # the table is measured on the fp32 kernels
@@ -93,15 +93,15 @@ def main():
                 lib.rib_set_choice(h, B, H, W, name.encode(), -1, 1)
             else:
                 lib.rib_set_choice(h, B, H, W, name.encode(), best[1], best[2])
-                chosen[name] = geoms[best[1]][:10] + [best[2], geoms[best[1]][10]]
+                chosen[name] = geoms[best[1]][:10] + [best[2], geoms[best[1]][10], geoms[best[1]][11]]
             total_before += base; total_after += best[0]
             results.sort()
             report.append({"shape": [B, H, W], "op": name, "default_us": base, "default": tile0, "best_us": best[0],
-                           "best": (geoms[best[1]][:10] + [best[2], geoms[best[1]][10]]) if best[1] is not None else None,
+                           "best": (geoms[best[1]][:10] + [best[2], geoms[best[1]][10], geoms[best[1]][11]]) if best[1] is not None else None,
                            "tflops_best": flops / best[0] / 1e6, "top": [(round(t, 1), geoms[v], k) for t, v, k in results[:4]]})
             print("%-46s default %7.1f us  best %7.1f us (%5.1f TF)  %s" % (
                 name[-46:], base, best[0], flops / best[0] / 1e6,
-                ("geom %s ksplit %d kw %d" % (geoms[best[1]][:6], best[2], geoms[best[1]][10])) if best[1] is not None else "model choice"), flush=True)
+                ("geom %s ksplit %d kw %d tb %d" % (geoms[best[1]][:6], best[2], geoms[best[1]][10], geoms[best[1]][11])) if best[1] is not None else "model choice"), flush=True)
         print("# %dx%d B=%d: %d ops, default %.0f us -> tuned %.0f us (%.1f s)" % (H, W, B, len(ops), total_before, total_after, time.time() - t_start))
         table["%d,%d,%d" % (B, H, W)] = chosen
     tuning.save(table, args.out)
