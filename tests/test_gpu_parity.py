@@ -373,3 +373,45 @@ def test_rasteriser_rejects_bad_tables():
         G.rasterise(strokes, bad, w, r, 32, 48)
     with pytest.raises(_native.RibError):
         G.rasterise(strokes, peaks[:, :5], w, r, 32, 48)          # 3 + 5 != label_nc
+
+
+def test_every_kernel_variant_is_correct_wherever_it_fits():
+    """Forces, on representative launches (3x3 with a fused 1x1 shortcut, stride 2, upsampled gather,
+    1x1, 16-column, SPADE), every tile variant x split-K that the plan accepts - including the
+    in-workgroup split-K (KW) and three-slices-per-barrier (TB) twins - and checks the frame against
+    the plan's default choice.  A variant that does not fit a launch is rejected by the plan builder."""
+    import ctypes as C
+    from render_in_between_amd import _native
+    spec, sd, _ = build("full", 0)
+    G = rib.Generator(rib.hsm_gen_config(), use_tuning=False).eval()
+    G.load_state_dict(sd)
+    lib, h = G._lib, G._h
+    B, H, W = 1, 64, 64
+    label, fake, prev = synth.make_inputs(spec, B, H, W, 3)
+    img0, mask0 = [t.clone() for t in G(label, None, fake, prev)]
+    R = oracle(spec, sd)
+    ri, rm = R(label, None, fake, prev)
+    assert (img0.cpu() - ri).abs().max() < TOL and (mask0.cpu() - rm).abs().max() < TOL
+    ops = ["down_1.conv_block_1", "ref_embedding.down_1", "flow_network_temp.up_flow.3", "res_0.conv_block_0",
+           "flow_network_temp.res_flow.0.conv_block_s", "conv_img", "down_0.0.spade", "up_3.1.spade", "flow_network_temp.down_lbl.0"]
+    g12 = (C.c_int * 12)()
+    tried = accepted = 0
+    seen_kw = seen_tb = 0
+    for name in ops:
+        for vi in range(lib.rib_num_variants()):
+            if lib.rib_variant_info(vi, g12) != 0:
+                continue                                   # bf16 twins are covered by the bf16 test
+            for ks in (1, 2, 4):
+                tried += 1
+                assert lib.rib_set_choice(h, B, H, W, name.encode(), vi, ks) == 0
+                try:
+                    img, mask = G(label, None, fake, prev)
+                except _native.RibError:
+                    continue                               # does not fit this launch
+                accepted += 1
+                seen_kw += g12[10] > 1
+                seen_tb += g12[11] > 1
+                e = max(float((img - img0).abs().max()), float((mask - mask0).abs().max()))
+                assert e < 5e-5, (name, list(g12), ks, e)
+        assert lib.rib_set_choice(h, B, H, W, name.encode(), -1, 1) == 0
+    assert accepted > 150 and seen_kw > 10 and seen_tb > 10, (tried, accepted, seen_kw, seen_tb)
