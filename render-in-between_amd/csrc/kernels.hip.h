@@ -663,12 +663,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           const int ox = tx0 + row % FRW;
           if (vvalid && oy < p.Hout && ox < p.Wout) {
             const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-            const float xv = p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c];
+            const float xv = (RIB_EXP & 8) ? 1.f : p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c];
             const float gamma = acc[mf][2 * q][r] + bg;
             const float beta = acc[mf][2 * q + 1][r] + bb;
             float o = (xv * sc + sh) * (1.f + gamma) + beta;
             o = apply_act(o, act);
-            yout[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c] = o;
+            if (!(RIB_EXP & 16) || o == 123.456f) yout[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c] = o;
           }
         }
       }
