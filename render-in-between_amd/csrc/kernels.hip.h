@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RIB_UPS_ROLL
+#define RIB_UPS_ROLL 0   // phase-decomposed upsample conv: 0 = 16 steps fully unrolled, 1 = taps of a phase rolled
+#endif
 #ifndef RIB_EXP
 #define RIB_EXP 0   // elimination switches for tools/probes/igemm_harness.hip; 0 in the product build
 #endif
@@ -112,8 +115,12 @@ struct IgemmGeom {
   static constexpr int FRH = 32 / FRW;
   static constexpr int TH = FRH * MF * WM;
   static constexpr int TW = FRW;
-  static constexpr int IH = UPS ? (TH / 2 + 2) : ((TH - 1) * STRIDE + KS);
-  static constexpr int IW = UPS ? (TW / 2 + 2) : ((TW - 1) * STRIDE + KS);
+  // UPS (3x3 on a nearest-x2-upsampled input) runs as four 2x2 "phase" convolutions of the stored
+  // half-resolution input (see k_igemm): the tile is TH x TW SOURCE pixels = 2TH x 2TW output pixels,
+  // its halo is the 3x3 halo of the source tile, and there are 4 phases x 4 taps = 16 filter slices
+  static constexpr int PH = UPS ? 4 : 1;
+  static constexpr int IH = UPS ? (TH + 2) : ((TH - 1) * STRIDE + KS);
+  static constexpr int IW = UPS ? (TW + 2) : ((TW - 1) * STRIDE + KS);
   static constexpr int CK = BK + 4;            // padded LDS row: conflict-free ds_read_b128
   // NF == 0 selects the 16-column path (v_mfma_f32_16x16x4_f32) for layers with <= 16 output
   // channels: no half-empty 32-column fragments
@@ -125,7 +132,7 @@ struct IgemmGeom {
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   static constexpr int SMEM0 = SA + 2 * TB * SB > SRED ? SA + 2 * TB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
-  static constexpr int TAPS = KS * KS;
+  static constexpr int TAPS = UPS ? 16 : KS * KS;   // filter slices per channel chunk (row stride of w)
 };
 
 // AUX / PRO: whether the fused-1x1-shortcut loop and the input prologue are compiled in.  They are
@@ -138,6 +145,15 @@ struct IgemmGeom {
 // the staged input tile and filter slices, each group runs 1/KW of every tap's channel steps, and the
 // partial accumulators are summed through LDS before the epilogue.  Gives an under-filled launch KW x
 // the wavefronts without the slab round trip and the second launch of grid-level split-K.
+// UPS: a 3x3 convolution of a nearest-x2-upsampled tensor (nn.Upsample(2) -> Conv2dBlock, PGNR/models/
+// generator.py:480).  Output pixel (2Y+py, 2X+px) reads upsampled rows 2Y+py-1+dy, i.e. source rows
+// Y-1+((py+dy)>>1): only TWO distinct source rows (and columns) per phase (py, px), so the nine taps
+// collapse to a 2x2 filter per phase whose entries are sums of the original taps
+//   py = 0: rows {Y-1: w[0], Y: w[1]+w[2]}     py = 1: rows {Y: w[0]+w[1], Y+1: w[2]}   (same along x)
+// (summed on the host, rib_finalize_weights): 4/9 of the matrix work and the same zero padding (source
+// row -1 / H is exactly where the upsampled row -1 / 2H falls).  A workgroup owns a TH x TW tile of
+// SOURCE pixels and keeps four accumulator sets, one per phase; filter slice t = phase*4 + a*2 + b
+// multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
   static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0), "16-column path: 8x16-style tiles only");
-  static_assert(!UPS || (STRIDE == 1 && KS == 3), "upsample gather only for 3x3 stride 1");
+  static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && TB == 1 && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
+  constexpr int PH = G::PH;
   static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   float* sA = smem;
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 
   // input-tile origin in stored-input coordinates
   int iy0, ix0;
-  if (UPS) { iy0 = ty0 / 2 - 1; ix0 = tx0 / 2 - 1; }
+  if (UPS) { iy0 = ty0 - 1; ix0 = tx0 - 1; }   // ty0 / tx0 are SOURCE coordinates in phase mode
   else { iy0 = ty0 * STRIDE - (KS / 2); ix0 = tx0 * STRIDE - (KS / 2); }
 
   // per-lane tile pixel of each M fragment
@@ -185,9 +202,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) fy[mf] = (wm * MF + mf) * G::FRH + li / FRW;
 
-  f32x16 acc[MF][NFE];
+  f32x16 acc[PH * MF][NFE];   // UPS: accumulator set ph*MF + mf belongs to phase ph = py*2 + px
   // experiment (RIB_EXP bit 2): two interleaved accumulation chains for single-fragment waves
-  constexpr bool DUAL = (RIB_EXP & 4) && !BF16 && !N16 && MF * NFE == 1;
+  constexpr bool DUAL = (RIB_EXP & 4) && !BF16 && !N16 && !UPS && MF * NFE == 1;
   f32x16 accb;
   if (DUAL) {
 #pragma unroll
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   f32x4 acc16[MF][2];     // 16-column path: two 16-pixel sub-fragments (tile rows) per 32-pixel block
   if (!N16) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < PH * MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < NFE; ++nf)
 #pragma unroll
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   };
 
   // one tap of one chunk: (BK/8) x {fragment reads, MF*NF*4 MFMAs} on the shifted LDS window
-  auto compute_tap = [&](int dy, int dx, int buf) {
+  auto compute_tap = [&](int dy, int dx, int buf, int ph = 0) {
     if constexpr (N16) {
       // v_mfma_f32_16x16x4_f32: lane l holds A[pixel l&15][k = l>>4] and B[k = l>>4][column l&15];
       // one float4 per lane (channels 4*(l>>4) .. +3 of a 16-channel step) feeds 4 MFMAs
@@ -342,9 +359,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     int aoff[MF];   // LDS float offset of this lane's pixel in the (dy, dx) window
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      int r, c;
-      if (UPS) { r = ((fy[mf] + dy - 1) >> 1) + 1; c = ((fx + dx - 1) >> 1) + 1; }
-      else { r = fy[mf] * STRIDE + dy; c = fx * STRIDE + dx; }
+      const int r = fy[mf] * STRIDE + dy, c = fx * STRIDE + dx;
       aoff[mf] = (r * G::IW + c) * G::CK;
     }
     const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int nf = 0; nf < NFE; ++nf)
-              acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+              acc[ph * MF + mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[ph * MF + mf][nf], 0, 0, 0);
         }
         return;
       }
@@ -394,16 +409,56 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
           for (int nf = 0; nf < NFE; ++nf) {
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, acc[mf][nf], 0, 0, 0);
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, acc[mf][nf], 0, 0, 0);
+            f32x16& d = acc[ph * MF + mf][nf];
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].x, b[nf].x, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].y, b[nf].y, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].z, b[nf].z, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf].w, b[nf].w, d, 0, 0, 0);
           }
       }
     }
   };
 
-  if constexpr (TB == 3) {
+  if constexpr (UPS) {
+    // 16 (phase, tap) steps per chunk, fully unrolled so that the accumulator set is a compile-time choice
+    loadB(kc_begin, 0);
+    prefetchA(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; kc += BK) {
+      __syncthreads();
+      writeA(false);
+#if RIB_UPS_ROLL
+      // phases unrolled (the accumulator set must be a compile-time choice), the four taps of a phase rolled
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll 1
+        for (int tt = 0; tt < 4; ++tt) {
+          const int buf = tt & 1;
+          storeB(buf);
+          {
+            int nt = ph * 4 + tt + 1, nkc = kc;
+            if (nt == 16) { nt = 0; nkc = kc + BK; }
+            if (nkc < kc_end) loadB(nkc, nt);
+          }
+          if (ph == 0 && tt == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+          __syncthreads();
+          compute_tap((ph >> 1) + (tt >> 1), (ph & 1) + (tt & 1), buf, ph);
+        }
+      }
+#else
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int buf = t & 1;
+        storeB(buf);
+        if (t < 15) loadB(kc, t + 1);
+        else if (kc + BK < kc_end) loadB(kc + BK, 0);
+        if (t == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+        __syncthreads();
+        const int ph = t >> 2;
+        compute_tap((ph >> 1) + ((t >> 1) & 1), (ph & 1) + (t & 1), buf, ph);
+      }
+#endif
+    }
+  } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
     int stage = 0;
@@ -568,14 +623,17 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     for (int nf = 0; nf < NF; ++nf) {
       const int col = n0 + (wn * NF + nf) * 32 + li;
 #pragma unroll
+      for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
-          const int ox = tx0 + row % FRW;
+          int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          int ox = tx0 + row % FRW;
+          if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
           if (col < p.CoutPad && oy < p.Hout && ox < p.Wout)
-            slab[((size_t)oy * p.Wout + ox) * p.CoutPad + col] = acc[mf][nf][r];
+            slab[((size_t)oy * p.Wout + ox) * p.CoutPad + col] = acc[ph * MF + mf][nf][r];
         }
       }
     }
@@ -589,15 +647,18 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       const bool cvalid = col < p.Cout;
       const float bv = (col < p.CoutPad) ? p.bias[col] : 0.f;
 #pragma unroll
+      for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
-          const int ox = tx0 + row % FRW;
+          int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          int ox = tx0 + row % FRW;
+          if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }   // phase ph of source pixel (oy, ox)
           if (cvalid && oy < p.Hout && ox < p.Wout) {
             const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
-            float v = acc[mf][nf][r] + bv;
+            float v = acc[ph * MF + mf][nf][r] + bv;
             if (p.res) {
               const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : pix;
               v += p.res[rpix * p.resC + col];

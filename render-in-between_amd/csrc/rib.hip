@@ -59,6 +59,10 @@ struct ConvDef {
   // device blob offsets (floats), filled by finalize
   size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;
   size_t fb_off = 0;   // conv_block_1 of a learned-shortcut SPADE block: bias + shortcut bias (fused launch)
+  // convolution of a nearest-x2-upsampled tensor (mask network, generator.py:480): the launch runs on the
+  // four 2x2 phase filters [CoutPad][16 = phase*4 + a*2 + b][CinPad] at wp_off (sums of the taps at w_off)
+  bool ups_in = false;
+  size_t wp_off = 0;
   int cinp = 0, coutp = 0;
 };
 
@@ -136,7 +140,7 @@ std::vector<ConvDef> build_inventory(const Cfg& g) {
   for (int i = 0; i < c.mask_res_blocks; ++i) add_mask_block(L, m + ".res_flow." + std::to_string(i), i == 0 ? ch * 2 : ch, ch);
   for (int j = 0; j < c.mask_down; ++j) {
     const int i = c.mask_down - 1 - j;
-    ConvDef d; d.name = m + ".up_flow." + std::to_string(2 * j + 1); d.cin = g.mask_nf(i + 1); d.cout = g.mask_nf(i); d.in_affine = true; L.push_back(d);
+    ConvDef d; d.name = m + ".up_flow." + std::to_string(2 * j + 1); d.cin = g.mask_nf(i + 1); d.cout = g.mask_nf(i); d.in_affine = true; d.ups_in = true; L.push_back(d);
   }
   { ConvDef d; d.name = m + ".conv_mask.0"; d.cin = c.mask_filters; d.cout = 1; d.spectral = false; L.push_back(d); }
   return L;
@@ -158,7 +162,7 @@ struct Variant {
   int TW() const { return FRW; }
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
-    const int ih = UPS ? TH() / 2 + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() / 2 + 2 : (TW() - 1) * STRIDE + KS;
+    const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int main_loop = (ih * iw * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
@@ -216,11 +220,13 @@ const Variant kVariants[] = {
     RIB_V(8, 2, 2, 1, 1, 16, 2, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 2, 3, false, false),
     RIB_V(16, 4, 1, 1, 1, 16, 2, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 2, 3, false, false),
     RIB_V(8, 2, 2, 2, 1, 16, 2, 3, false, false),
-    // 3x3 on a nearest-x2-upsampled input
+    // 3x3 on a nearest-x2-upsampled input, phase-decomposed: the tile is in SOURCE pixels, four
+    // accumulator sets per wave (MF * NF <= 2 keeps them within 128 registers)
     RIB_V(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 32, 1, 3, true, false),
     RIB_V(16, 4, 1, 1, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 16, 1, 3, true, false),
     RIB_V(16, 4, 1, 2, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 2, 1, 32, 1, 3, true, false),
-    RIB_V(16, 4, 1, 2, 2, 32, 1, 3, true, false),
+    RIB_V(8, 2, 2, 1, 1, 32, 1, 3, true, false),   RIB_V(8, 2, 2, 1, 1, 16, 1, 3, true, false),
+    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, true, false),
     // 1x1
     RIB_V(16, 4, 1, 1, 1, 16, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 1, false, false),
     RIB_V(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, false),
@@ -238,14 +244,12 @@ const Variant kVariants[] = {
     RIB_VK(16, 4, 1, 1, 1, 16, 1, 3, false, 2),
     RIB_VK(8, 2, 2, 1, 1, 32, 2, 3, false, 2),  RIB_VK(8, 2, 2, 1, 1, 32, 2, 3, false, 4),
     RIB_VK(8, 2, 2, 1, 1, 16, 2, 3, false, 2),  RIB_VK(16, 4, 1, 1, 1, 16, 2, 3, false, 2),
-    RIB_VK(16, 4, 1, 1, 1, 32, 1, 3, true, 2),  RIB_VK(16, 4, 1, 2, 1, 32, 1, 3, true, 2),
     RIB_VK(16, 4, 1, 1, 1, 32, 1, 1, false, 2), RIB_VK(16, 4, 1, 1, 2, 32, 1, 1, false, 2),
     RIB_VK(16, 4, 1, 1, 2, 64, 1, 1, false, 2), RIB_VK(8, 2, 2, 1, 1, 64, 1, 1, false, 2),
     // ---- three-taps-per-barrier twins for launches with LDS to spare (<= 2 workgroups per CU) ----
     RIB_VT(16, 4, 1, 1, 1, 32, 1, false), RIB_VT(16, 4, 1, 1, 2, 32, 1, false), RIB_VT(16, 4, 1, 2, 1, 32, 1, false),
     RIB_VT(8, 2, 2, 1, 1, 32, 1, false),  RIB_VT(16, 4, 1, 1, 1, 16, 1, false), RIB_VT(16, 4, 1, 1, 2, 16, 1, false),
     RIB_VT(8, 2, 2, 1, 1, 32, 2, false),  RIB_VT(8, 2, 2, 1, 1, 16, 2, false),  RIB_VT(16, 4, 1, 1, 2, 16, 2, false),
-    RIB_VT(16, 4, 1, 1, 1, 32, 1, true),  RIB_VT(16, 4, 1, 2, 1, 32, 1, true),  RIB_VT(16, 4, 1, 1, 2, 32, 1, true),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
@@ -295,14 +299,16 @@ Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, in
     // in-workgroup split-K only where the tile grid alone cannot fill the chip
     if ((v.KW > 1 || v.TB > 1) && (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW()) * ((ncols + v.BN() - 1) / v.BN()) * B >= 512) continue;
     const int nchunks = Cin / BK;
-    const long tiles = (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW());
+    // phase-decomposed upsample conv: tiles of SOURCE pixels, 16 (phase, tap) steps per chunk
+    const int Ht = ups ? Hout / 2 : Hout, Wt = ups ? Wout / 2 : Wout;
+    const long tiles = (long)((Ht + v.TH() - 1) / v.TH()) * ((Wt + v.TW() - 1) / v.TW());
     const long ntiles = v.NF == 0 ? 1 : (ncols + v.BN() - 1) / v.BN();
-    const int occ = std::max(1, std::min(v.MF * v.NF >= 4 ? 4 : 6, 160 * 1024 / v.lds_bytes()));
+    const int occ = std::max(1, std::min(v.MF * v.NF * (ups ? 4 : 1) >= 4 ? 4 : 6, 160 * 1024 / v.lds_bytes()));
     for (int S : kSplits) {
       if (S > nchunks || (S > 1 && (!allow_split || v.NF == 0))) break;
       const long wgs = tiles * ntiles * B * S;
       const int chunks = (nchunks + S - 1) / S;
-      const int taps = ks * ks;
+      const int taps = ups ? 16 : ks * ks;
       const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0
                                         : (v.BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
@@ -452,6 +458,7 @@ void assign_weight_layout(rib_handle* h) {
     c.cinp = pad8(c.cin);
     c.coutp = pad32(c.cout);
     c.w_off = take((size_t)c.coutp * c.ks * c.ks * c.cinp);
+    if (c.ups_in) c.wp_off = take((size_t)c.coutp * 16 * c.cinp);
     c.b_off = take(c.coutp);
     if (c.in_affine) { c.g_off = take(c.coutp); c.be_off = take(c.coutp); }
     if (c.spade_cond && c.name.size() > 13 && c.name.compare(c.name.size() - 13, 13, ".conv_block_1") == 0 &&
@@ -610,11 +617,14 @@ struct Builder {
     p.pro_ld = a.pro ? a.pro->ld : 0; p.pro_lrelu = a.pro_lrelu ? 1 : 0;
     p.CoutPad = c.coutp;
     p.Hout = Hout; p.Wout = Wout;
-    p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+    // phase-decomposed upsample conv: tiles of SOURCE pixels (each yields a 2TH x 2TW output patch)
+    p.tilesX = ((a.ups ? a.in.W : Wout) + v->TW() - 1) / v->TW(); p.tilesY = ((a.ups ? a.in.H : Hout) + v->TH() - 1) / v->TH();
+    p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+    if (a.ups && (!c.ups_in || c.ks != 3 || c.stride != 1)) { error = opname + ": no phase filters for this upsample convolution"; return false; }
     p.act = a.act; p.ksplit = S;
     op.x = WS(a.in.off);
     if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
-    op.w = WT(c.w_off); op.bias = WT(c.b_off);
+    op.w = WT(a.ups ? c.wp_off : c.w_off); op.bias = WT(c.b_off);
     double aux_flops = 0.0;
     if (a.aux) {
       if (c.ks != 3 || c.stride != 1 || a.ups || !c.fb_off || a.aux->ks != 1 || a.aux->coutp != c.coutp || a.aux_in.Cp != a.aux->cinp ||
@@ -1264,6 +1274,26 @@ int rib_finalize_weights(rib_handle* h) {
           blob[c.w_off + ((size_t)o * taps + t) * c.cinp + i] = c.spectral ? wv / inv : wv;
         }
     for (int o = 0; o < c.cout; ++o) blob[c.b_off + o] = b[o];
+    if (c.ups_in) {
+      // phase filters of the upsample convolution (k_igemm, UPS): along each axis, phase p and tap a
+      // sum the original taps   p = 0: a = 0 <- {0}, a = 1 <- {1, 2};   p = 1: a = 0 <- {0, 1}, a = 1 <- {2}
+      // (fp32 sums of the folded filters, in a fixed dy-major order)
+      static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};   // [p][a]: inclusive tap range
+      for (int o = 0; o < c.cout; ++o)
+        for (int ph = 0; ph < 4; ++ph)
+          for (int a = 0; a < 2; ++a)
+            for (int bb = 0; bb < 2; ++bb) {
+              const int py = ph >> 1, px = ph & 1;
+              float* dst = &blob[c.wp_off + ((size_t)o * 16 + ph * 4 + a * 2 + bb) * c.cinp];
+              for (int i = 0; i < c.cin; ++i) {
+                float acc = 0.f;
+                for (int dy = lo[py][a]; dy <= hi[py][a]; ++dy)
+                  for (int dx = lo[px][bb]; dx <= hi[px][bb]; ++dx)
+                    acc += blob[c.w_off + ((size_t)o * 9 + dy * 3 + dx) * c.cinp + i];
+                dst[i] = acc;
+              }
+            }
+    }
     if (c.in_affine) {
       const std::vector<float>& gm = *tensor_data(h, c.name + ".layers.norm.weight");
       const std::vector<float>& bt = *tensor_data(h, c.name + ".layers.norm.bias");

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", type=str, default=tuning.TUNING_PATH)
     ap.add_argument("--report", type=str, default=None)
+    ap.add_argument("--only", type=str, default=None,
+                    help="re-tune only the launches whose name contains this substring; other entries of the shape are kept")
     args = ap.parse_args()
     lib = _native.lib()
     cfg = rib.hsm_gen_config()
@@ -57,7 +59,7 @@ def main():
         for i in range(lib.rib_num_launches(h, B, H, W)):
             lib.rib_debug_launch_info(h, B, H, W, i, buf, 512)
             name, kclass, grid, tile, flops = buf.value.decode().split("|")
-            if int(kclass) in (0, 1):
+            if int(kclass) in (0, 1) and (args.only is None or args.only in name):
                 ops.append((name, int(kclass), float(flops), tile))
         usec = C.c_double()
         chosen = {}
@@ -103,7 +105,14 @@ def main():
                 name[-46:], base, best[0], flops / best[0] / 1e6,
                 ("geom %s ksplit %d kw %d tb %d" % (geoms[best[1]][:6], best[2], geoms[best[1]][10], geoms[best[1]][11])) if best[1] is not None else "model choice"), flush=True)
         print("# %dx%d B=%d: %d ops, default %.0f us -> tuned %.0f us (%.1f s)" % (H, W, B, len(ops), total_before, total_after, time.time() - t_start))
-        table["%d,%d,%d" % (B, H, W)] = chosen
+        key = "%d,%d,%d" % (B, H, W)
+        if args.only is None:
+            table[key] = chosen
+        else:
+            entry = table.setdefault(key, {})
+            for name, _, _, _ in ops:
+                entry.pop(name, None)          # "model choice" results drop a stale entry
+            entry.update(chosen)
     tuning.save(table, args.out)
     if args.report:
         with open(args.report, "w") as f:
