@@ -15,6 +15,10 @@ SRC = os.path.join(HERE, "rib.hip")
 DEPS = [SRC, os.path.join(HERE, "kernels.hip.h"), os.path.join(HERE, "raster.hip.h"),
         os.path.join(HERE, "..", "..", "include", "rib.h")]
 OUT = os.path.join(HERE, "librib.so")
+# stage 1 (motion transformer, include/rib_motion.h) is its own small library
+MOTION_SRC = os.path.join(HERE, "motion.hip")
+MOTION_DEPS = [MOTION_SRC, os.path.join(HERE, "..", "..", "include", "rib_motion.h")]
+MOTION_OUT = os.path.join(HERE, "libribmotion.so")
 
 
 def hipcc_path():
@@ -24,22 +28,27 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (need the ROCm toolchain to build librib.so)")
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def needs_build(out=OUT, deps=DEPS):
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return OUT
+def _compile(src, out, verbose):
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           SRC, "-o", OUT + ".tmp"]
+           src, "-o", out + ".tmp"]
     if verbose:
         print("[rib build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)
-    os.replace(OUT + ".tmp", OUT)
+    os.replace(out + ".tmp", out)
+
+
+def build(force=False, verbose=True):
+    if force or needs_build(MOTION_OUT, MOTION_DEPS):
+        _compile(MOTION_SRC, MOTION_OUT, verbose)
+    if force or needs_build():
+        _compile(SRC, OUT, verbose)
     return OUT
 
 

@@ -1,0 +1,198 @@
+"""CPU suite for stage 1, the motion transformer: the oracle and the product's host
+plumbing against the fixtures made by the reference's own code (tests/golden/make_golden_motion.py),
+and the C ABI of include/rib_motion.h (loads, exports every declared symbol, strict-load errors on a
+host-only handle).  No compute entry point is called here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import render_in_between_amd  # noqa: F401
+from render_in_between_amd.motion import MotionSpec, state_dict_spec, synth, pose_io, _native
+from oracle import motion_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NET_CASES = ["a", "b", "c", "d"]
+TOL = 2e-5    # oracle vs reference outputs (measured <= 4.1e-6, tests/golden/motion_report.json)
+
+
+def load_net_case(name):
+    z = np.load(os.path.join(GOLDEN, "motion_net_%s.npz" % name))
+    cfg = json.loads(str(z["spec"]))
+    return MotionSpec(**cfg), cfg, z
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_native.LIB_PATH):
+        from importlib import util
+        spec = util.spec_from_file_location("rib_build", os.path.join(os.path.dirname(_native.LIB_PATH), "build.py"))
+        mod = util.module_from_spec(spec); spec.loader.exec_module(mod)
+        mod.build()
+    return _native.lib()
+
+
+def test_state_dict_layout_matches_reference_keys():
+    with open(os.path.join(GOLDEN, "motion_state_dict_keys.json")) as f:
+        ref = [(k, tuple(s)) for k, s in json.load(f)]
+    assert state_dict_spec(MotionSpec()) == ref
+    assert len(ref) == 188
+
+
+@pytest.mark.parametrize("name", NET_CASES)
+def test_oracle_reproduces_reference_transformer(name):
+    spec, cfg, z = load_net_case(name)
+    sd = synth.make_state_dict(spec, int(z["seed"]))
+    src, tgt = torch.from_numpy(z["src"]), torch.from_numpy(z["tgt"])
+    sm, tm = torch.from_numpy(z["src_mask"]), torch.from_numpy(z["tgt_mask"])
+    npf = spec.pos_hidden_dim // 2
+    j, r = motion_ref.transformer_forward(sd, cfg, src, sm, motion_ref.position_embedding_sine(sm, npf), tgt, tm,
+                                          motion_ref.position_embedding_sine(tm, npf), int(z["rate"]))
+    assert float((j - torch.from_numpy(z["joints"])).abs().max()) <= TOL
+    assert float((r - torch.from_numpy(z["reco"])).abs().max()) <= TOL
+
+
+def test_interpolate_embedding_known_answer():
+    x = torch.arange(9, dtype=torch.float32).view(9, 1, 1) ** 2
+    y = motion_ref.interpolate_embedding(x, 4)
+    # key frames 0, 4, 8 hold 0, 16, 64; frames in between are the straight line between them
+    assert torch.allclose(y.view(-1), torch.tensor([0., 4., 8., 12., 16., 28., 40., 52., 64.]))
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_pose_plumbing_is_bit_exact_against_reference(name, impl):
+    z = np.load(os.path.join(GOLDEN, "motion_pose_%s.npz" % name))
+    jdir = os.path.join(GOLDEN, "motion_json", name)
+    rate = int(z["rate"])
+    clips = pose_io.OpenPoseClips({})
+    if impl == "oracle":
+        (scale, offset, conf), inp, interp, em, dm = motion_ref.get_openpose_data(jdir, rate, clips.mean_pose, clips.std_pose)
+        out = motion_ref.post_process(torch.from_numpy(z["pred"]), clips.mean_pose, clips.std_pose)
+        lin = motion_ref.post_process(interp.unsqueeze(0), clips.mean_pose, clips.std_pose)
+    else:
+        (scale, offset, conf), inp, interp, em, dm = clips.get_openpose_data(jdir, rate)
+        ev = pose_io.Evaluator({})
+        out = ev._post_process(torch.from_numpy(z["pred"]))
+        lin = ev._post_process(interp.unsqueeze(0))
+    assert (scale, offset) == (512, 256)
+    assert np.array_equal(inp.numpy(), z["input"]) and np.array_equal(interp.numpy(), z["interp"])
+    assert np.array_equal(em.numpy(), z["encoder_mask"]) and np.array_equal(dm.numpy(), z["decoder_mask"])
+    assert np.array_equal(conf, z["conf"])
+    assert np.array_equal(out, z["out"]) and np.array_equal(lin, z["linear"])
+    assert em.sum() == len(em) - ((len(em) - 1) // rate + 1)          # exactly the key frames are visible
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_written_openpose_json_matches_reference(tmp_path, impl):
+    z = np.load(os.path.join(GOLDEN, "motion_pose_b.npz"))
+    files = [str(f) for f in z["files"]]
+    if impl == "oracle":
+        docs = motion_ref.motion_to_openpose_dicts(z["out"], z["conf"], 512, 256)
+        docs = json.loads(json.dumps(docs))
+    else:
+        pose_io.motion2openpose(z["out"], z["conf"], str(tmp_path / "pred"), scale=512, offset=256, sample_rate=int(z["rate"]))
+        assert sorted(os.listdir(tmp_path / "pred")) == files
+        docs = [json.load(open(tmp_path / "pred" / f)) for f in files]
+    assert docs[0] == json.loads(str(z["doc_first"]))
+    assert docs[len(docs) // 2] == json.loads(str(z["doc_mid"]))
+
+
+def test_pose_plumbing_edge_cases(tmp_path):
+    # nobody in any frame: zeros everywhere, all confidences 0
+    d = tmp_path / "empty"
+    d.mkdir()
+    for i in range(3):
+        json.dump({"version": 1.3, "people": []}, open(d / ("%06d_keypoints.json" % i), "w"))
+    for fn in (motion_ref.openpose2motion, pose_io.openpose2motion):
+        m, c, (s, o) = fn(str(d), scale=512, offset=256)
+        assert m.shape == (19, 2, 3) and c.shape == (19, 1, 3) and not m.any() and not c.any()
+    # rate 1: no interpolation rounds, every frame is a key frame
+    z = np.load(os.path.join(GOLDEN, "motion_pose_a.npz"))
+    clips = pose_io.OpenPoseClips({})
+    _, inp, interp, em, dm = clips.get_openpose_data(os.path.join(GOLDEN, "motion_json", "a"), 1)
+    assert inp.shape[-1] == 5 and not em.any() and torch.equal(inp, interp)
+    assert np.array_equal(interp.numpy(), z["interp"][:, ::8])
+
+
+def test_spec_rejects_unsupported_variants():
+    with pytest.raises(ValueError):
+        MotionSpec.from_cfg({"transformer": {"activation": "glu"}})
+    with pytest.raises(ValueError):
+        MotionSpec.from_cfg({"transformer": {"intermediate": True}})
+    with pytest.raises(ValueError):
+        MotionSpec.from_cfg({"transformer": {}, "pos_encode": {"position_embedding": "v3"}})
+    with pytest.raises(ValueError):
+        MotionSpec.from_cfg({"transformer": {"hidden_dim": 120, "nheads": 7}})
+    assert MotionSpec.from_cfg({"transformer": {"hidden_dim": 64, "nheads": 4}, "pos_encode": {"hidden_dim": 64}}).hidden_dim == 64
+
+
+# ---------------------------------------------------------------- C ABI, host-only
+def host_handle(lib, spec):
+    c = _native.RibmConfig(input_joints=spec.input_joints, hidden_dim=spec.hidden_dim, nheads=spec.nheads,
+                           dim_feedforward=spec.dim_feedforward, enc_layers=spec.enc_layers, dec_layers=spec.dec_layers,
+                           activation=_native.ACT_IDS[spec.activation], pre_norm=int(spec.pre_norm), two_stage=int(spec.two_stage))
+    h = C.c_void_p()
+    assert lib.ribm_create(C.byref(c), -1, C.byref(h)) == 0, lib.ribm_last_error(None)
+    return h
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "rib_motion.h")).read()
+    declared = set(re.findall(r"\b(ribm_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 11
+    for name in declared:
+        assert hasattr(lib, name), "libribmotion.so does not export %s" % name
+    assert set(_native.SIGNATURES) == declared
+    assert re.findall(r"int32_t\s+(\w+);", hdr) == [n for n, _ in _native.RibmConfig._fields_]
+
+
+@pytest.mark.parametrize("over", [{}, dict(pre_norm=False, enc_layers=2, dec_layers=1, hidden_dim=64, pos_hidden_dim=64, nheads=4)])
+def test_native_inventory_and_strict_load(lib, over):
+    spec = MotionSpec(**over)
+    h = host_handle(lib, spec)
+    want = state_dict_spec(spec)
+    name = C.c_char_p(); ndim = C.c_int(); dims = (C.c_int64 * 2)()
+    got = []
+    for i in range(lib.ribm_num_tensors(h)):
+        assert lib.ribm_tensor_info(h, i, C.byref(name), C.byref(ndim), dims) == 0
+        got.append((name.value.decode(), tuple(dims[j] for j in range(ndim.value))))
+    assert got == want
+    sd = synth.make_state_dict(spec, 3)
+    assert lib.ribm_finalize_weights(h) == -4 and b"missing key" in lib.ribm_last_error(h)
+    x = np.zeros((3, 3), np.float32); d = (C.c_int64 * 2)(3, 3)
+    assert lib.ribm_set_tensor(h, b"encoder.layers.0.bogus", x.ctypes.data_as(C.c_void_p), 2, d) == -1
+    assert b"unexpected key" in lib.ribm_last_error(h)
+    assert lib.ribm_set_tensor(h, b"input_embed.weight", x.ctypes.data_as(C.c_void_p), 2, d) == -1
+    assert b"size mismatch" in lib.ribm_last_error(h)
+    for k, v in sd.items():
+        t = v.contiguous(); dd = (C.c_int64 * t.dim())(*t.shape)
+        assert lib.ribm_set_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), dd) == 0
+    assert lib.ribm_finalize_weights(h) == 0
+    assert lib.ribm_weights_bytes(h) >= 4 * sum(int(np.prod(s)) for _, s in want)
+    assert lib.ribm_workspace_bytes(h, 1, 33) > 0
+    # a host-only handle refuses to launch
+    assert lib.ribm_forward(h, 1, 33, 8, *([None] * 9), 0, None) == -3
+    lib.ribm_destroy(h)
+
+
+def test_unsupported_native_configs_fail_loudly(lib):
+    for bad in (dict(hidden_dim=100, nheads=5), dict(hidden_dim=512), dict(dim_feedforward=4096), dict(activation=7)):
+        f = dict(input_joints=38, hidden_dim=128, nheads=8, dim_feedforward=256, enc_layers=6, dec_layers=6, activation=2, pre_norm=1, two_stage=1)
+        f.update(bad)
+        h = C.c_void_p()
+        assert lib.ribm_create(C.byref(_native.RibmConfig(**f)), -1, C.byref(h)) == -2
+        assert len(lib.ribm_last_error(None)) > 0
+
+
+def test_motion_model_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from render_in_between_amd.motion import model
+    with pytest.raises(RuntimeError):
+        model.MotionTransformer(MotionSpec())
