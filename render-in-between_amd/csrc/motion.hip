@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -44,7 +45,7 @@ struct Strides { long n, l, k; };   // element (n, l, k) of a logical [N][L][K] 
 struct LinParams {
   const float* x; Strides xs; int K;
   const float* ln_g; const float* ln_b;       // LayerNorm over K before the product (nullptr: none)
-  const float* pos; Strides ps; int pos_cols;  // x += pos for output columns < pos_cols (multiple of 128)
+  const float* pos; Strides ps; int pos_cols;  // x += pos for output columns < pos_cols (multiple of TN, or >= Nout)
   const float* wt; int ldw;                    // W^T [K][ldw], columns col0 .. col0+Nout of it
   const float* bias; int Nout;
   int act;                                     // -1 none, else RIBM_ACT_*
@@ -66,64 +67,149 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// grid (ceil(R / TM), ceil(Nout / 128)), block 128: thread = output column, TM rows per block
-__global__ __launch_bounds__(128) void km_linear(const LinParams p) {
+// grid (ceil(R / TM), ceil(Nout / TN)), block 256.  One global round trip per operand: the TM input rows
+// (whole K) and a KC x TN chunk of W^T are staged in LDS by all threads at once, then thread (column =
+// tid & 63, row pair = wave) runs its two dot products from LDS (conflict-free filter reads, broadcast
+// input reads).  A first version that walked W^T from global memory in the k loop spent 27 us per launch
+// waiting on 32 dependent batches of loads (profiles/r01_motion.md).
+constexpr int TN = 64, KC = 128;
+constexpr int WB = KC * TN / 256;      // filter values per thread and chunk
+__global__ __launch_bounds__(256) void km_linear(const LinParams p) {
   __shared__ float xs[TM][KMAX + 4];
+  __shared__ float wsm[KC][TN + 1];
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int r0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * 128;
+  const int n0 = blockIdx.y * TN;
   const int K = p.K;
-  for (int idx = tid; idx < TM * K; idx += 128) {
-    const int row = idx / K, k = idx - row * K;
-    const int r = r0 + row;
-    float v = 0.f;
-    if (r < p.R) { const int n = r / p.L, l = r - n * p.L; v = p.x[n * p.xs.n + l * p.xs.l + k * p.xs.k]; }
-    xs[row][k] = v;
+  const int col = n0 + lane;
+  const bool cvalid = col < p.Nout;
+  // ---- every global load that does not depend on another is issued up front, so that the launch pays ONE
+  // memory round trip (a load -> LDS store loop pays one per iteration: 15 us per launch, measured) ----
+  float wv[WB];     // first KC x TN chunk of W^T
+  const int kn0 = min(KC, K);
+#pragma unroll
+  for (int u = 0; u < WB; ++u) {
+    const int idx = u * 256 + tid;
+    const int kk = idx >> 6, cc = idx & 63;
+    wv[u] = (kk < kn0 && n0 + cc < p.Nout) ? p.wt[(size_t)kk * p.ldw + n0 + cc] : 0.f;
+  }
+  const float b = cvalid ? p.bias[col] : 0.f;
+  float resv[2] = {0.f, 0.f};
+  if (p.res && cvalid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = r0 + wave * 2 + i;
+      if (r < p.R) { const int n = r / p.L, l = r - n * p.L; resv[i] = p.res[n * p.rs.n + l * p.rs.l + col * p.rs.k]; }
+    }
+  }
+  const bool use_pos = p.pos && n0 < p.pos_cols;
+  const bool small = K <= 256;       // LayerNorm / positional inputs are hidden_dim wide: at most 8 values per thread
+  float xv[8], pv[8], gv[4], bv[4];
+  if (small) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid;
+      const int row = idx / K, k = idx - row * K;
+      const int r = r0 + row;
+      xv[u] = 0.f; pv[u] = 0.f;
+      if (idx < TM * K && r < p.R) {
+        const int n = r / p.L, l = r - n * p.L;
+        xv[u] = p.x[n * p.xs.n + l * p.xs.l + k * p.xs.k];
+        if (use_pos) pv[u] = p.pos[n * p.ps.n + l * p.ps.l + k * p.ps.k];
+      }
+    }
+    if (p.ln_g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = lane + u * 64; gv[u] = k < K ? p.ln_g[k] : 0.f; bv[u] = k < K ? p.ln_b[k] : 0.f; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < TM * K) { const int row = idx / K; xs[row][idx - row * K] = xv[u]; }
+    }
+  } else {
+    // wide reductions (the second FFN matrix): no LayerNorm / positional term on these inputs
+    for (int base = 0; base < TM * K; base += 256 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int row = idx / K, k = idx - row * K;
+        const int r = r0 + row;
+        xv[u] = 0.f;
+        if (idx < TM * K && r < p.R) { const int n = r / p.L, l = r - n * p.L; xv[u] = p.x[n * p.xs.n + l * p.xs.l + k * p.xs.k]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        if (idx < TM * K) { const int row = idx / K; xs[row][idx - row * K] = xv[u]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < WB; ++u) {
+    const int idx = u * 256 + tid;
+    wsm[idx >> 6][idx & 63] = wv[u];
   }
   __syncthreads();
-  if (p.ln_g) {
+  if (small && p.ln_g) {
     // nn.LayerNorm: biased variance over the last dim, (x - mean) / sqrt(var + eps) * g + b; two passes
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int row = wave * (TM / 2); row < (wave + 1) * (TM / 2); ++row) {
+    for (int row = wave * 2; row < wave * 2 + 2; ++row) {
       float s = 0.f;
       for (int k = lane; k < K; k += 64) s += xs[row][k];
       const float mean = wave_sum(s) / (float)K;
       float q = 0.f;
       for (int k = lane; k < K; k += 64) { const float d = xs[row][k] - mean; q += d * d; }
       const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + LN_EPS);
-      for (int k = lane; k < K; k += 64) xs[row][k] = (xs[row][k] - mean) * rstd * p.ln_g[k] + p.ln_b[k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = lane + u * 64; if (k < K) xs[row][k] = (xs[row][k] - mean) * rstd * gv[u] + bv[u]; }
     }
     __syncthreads();
   }
-  if (p.pos && n0 < p.pos_cols) {
-    for (int idx = tid; idx < TM * K; idx += 128) {
-      const int row = idx / K, k = idx - row * K;
-      const int r = r0 + row;
-      if (r < p.R) { const int n = r / p.L, l = r - n * p.L; xs[row][k] += p.pos[n * p.ps.n + l * p.ps.l + k * p.ps.k]; }
+  if (small && use_pos) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < TM * K) { const int row = idx / K; xs[row][idx - row * K] += pv[u]; }
     }
     __syncthreads();
   }
-  const int col = n0 + tid;
-  if (col >= p.Nout) return;
-  float acc[TM];
-  const float b = p.bias[col];
+  float acc0 = b, acc1 = b;
+  const float* x0 = xs[wave * 2];
+  const float* x1 = xs[wave * 2 + 1];
+  for (int kc = 0; kc < K; kc += KC) {
+    const int kn = min(KC, K - kc);
+    if (kc > 0) {
+      __syncthreads();     // every wave is done with the previous chunk of W^T
 #pragma unroll
-  for (int i = 0; i < TM; ++i) acc[i] = b;
-  const float* w = p.wt + col;
-#pragma unroll 4
-  for (int k = 0; k < K; ++k) {
-    const float wv = w[(size_t)k * p.ldw];      // coalesced across the 128 columns; broadcast LDS reads below
+      for (int u = 0; u < WB; ++u) {
+        const int idx = u * 256 + tid;
+        const int kk = idx >> 6, cc = idx & 63;
+        wv[u] = (kk < kn && n0 + cc < p.Nout) ? p.wt[(size_t)(kc + kk) * p.ldw + n0 + cc] : 0.f;
+      }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) acc[i] = fmaf(xs[i][k], wv, acc[i]);
+      for (int u = 0; u < WB; ++u) {
+        const int idx = u * 256 + tid;
+        wsm[idx >> 6][idx & 63] = wv[u];
+      }
+      __syncthreads();
+    }
+#pragma unroll 8
+    for (int kk = 0; kk < kn; ++kk) {
+      const float w = wsm[kk][lane];
+      acc0 = fmaf(x0[kc + kk], w, acc0);
+      acc1 = fmaf(x1[kc + kk], w, acc1);
+    }
   }
+  if (!cvalid) return;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int r = r0 + i;
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + wave * 2 + i;
     if (r >= p.R) break;
     const int n = r / p.L, l = r - n * p.L;
-    float v = acc[i];
+    float v = i == 0 ? acc0 : acc1;
     if (p.act >= 0) v = act_fn(v, p.act);
-    if (p.res) v += p.res[n * p.rs.n + l * p.rs.l + col * p.rs.k];
+    if (p.res) v += resv[i];
     p.y[n * p.ys.n + l * p.ys.l + col * p.ys.k] = v;
   }
 }
@@ -189,6 +275,109 @@ __global__ __launch_bounds__(64) void km_attention(const AttnParams p) {
     }
   }
 }
+
+// km_attention_tile: the same attention for clips whose score tile fits LDS (Lk <= ~1000 frames at head_dim 16;
+// the reference config trains on 321).  grid (ceil(Lq / QT), heads, N), block 256, QT = 256 / HD queries:
+//   1. thread = key: k_j in registers, scores of the QT queries against it -> S[QT][Lk] in LDS (masks as -inf)
+//   2. wave = query row: max, exp, sum over the row with wavefront shuffles (exact two-pass softmax)
+//   3. thread = (query, channel): out = (sum_j e_j v_j[d]) / sum_j e_j, V staged once in LDS
+// The thread-per-query kernel above needs 2 x Lk serial steps per wave (28 us at 65 frames, 135 us at 321);
+// here the longest chain is Lk / 4 fused multiply-adds.
+template <int HD>
+__global__ __launch_bounds__(256) void km_attention_tile(const AttnParams p) {
+  constexpr int QT = 256 / HD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Lk = p.Lk, SS = Lk + 1;
+  float* S = smem;                       // [QT][Lk + 1]
+  float* sv = S + QT * SS;               // [Lk][HD]
+  float* sq = sv + (size_t)Lk * HD;      // [QT][HD]
+  float* ssum = sq + QT * HD;            // [QT]
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * QT;
+  // the first key of this thread is fetched together with q and V: one memory round trip before the scores
+  float4 kpre[HD / 4];
+  if (tid < Lk) {
+    const float4* kp = reinterpret_cast<const float4*>(p.k + ((size_t)n * Lk + tid) * p.ldk + h * HD);
+#pragma unroll
+    for (int d4 = 0; d4 < HD / 4; ++d4) kpre[d4] = kp[d4];
+  }
+  const bool mpre = tid < Lk && p.kpm && p.kpm[(size_t)n * Lk + tid];
+  {
+    const int qi = tid / HD, d = tid - qi * HD;
+    const int i = q0 + qi;
+    sq[tid] = i < p.Lq ? p.q[((size_t)n * p.Lq + i) * p.ldq + h * HD + d] * p.scale : 0.f;
+  }
+  for (int base = 0; base < Lk * HD; base += 256 * 8) {   // batched loads, see km_linear
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      const int j = idx / HD, d = idx - j * HD;
+      v[u] = idx < Lk * HD ? p.v[((size_t)n * Lk + j) * p.ldv + h * HD + d] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < Lk * HD) sv[idx] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < Lk; j += 256) {
+    float kreg[HD];
+    const float4* kp = reinterpret_cast<const float4*>(p.k + ((size_t)n * Lk + j) * p.ldk + h * HD);
+#pragma unroll
+    for (int d4 = 0; d4 < HD / 4; ++d4) {
+      const float4 t = j == tid ? kpre[d4] : kp[d4];
+      kreg[d4 * 4] = t.x; kreg[d4 * 4 + 1] = t.y; kreg[d4 * 4 + 2] = t.z; kreg[d4 * 4 + 3] = t.w;
+    }
+    const bool masked = j == tid ? mpre : (p.kpm && p.kpm[(size_t)n * Lk + j]);
+#pragma unroll 4
+    for (int qi = 0; qi < QT; ++qi) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(sq[qi * HD + d], kreg[d], s);
+      if (masked || (p.diag && j == q0 + qi)) s = -INFINITY;
+      S[qi * SS + j] = s;
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int qi = wave; qi < QT; qi += 4) {
+    float* row = S + qi * SS;
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int j = lane; j < Lk; j += 64) { const float e = expf(row[j] - m); row[j] = e; sum += e; }   // all keys masked: NaN, as torch
+    sum = wave_sum(sum);
+    if (lane == 0) ssum[qi] = sum;
+  }
+  __syncthreads();
+  {
+    const int qi = tid / HD, d = tid - qi * HD;
+    const float* row = S + qi * SS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    for (; j + 3 < Lk; j += 4) {
+      a0 = fmaf(row[j], sv[(size_t)j * HD + d], a0);
+      a1 = fmaf(row[j + 1], sv[(size_t)(j + 1) * HD + d], a1);
+      a2 = fmaf(row[j + 2], sv[(size_t)(j + 2) * HD + d], a2);
+      a3 = fmaf(row[j + 3], sv[(size_t)(j + 3) * HD + d], a3);
+    }
+    for (; j < Lk; ++j) a0 = fmaf(row[j], sv[(size_t)j * HD + d], a0);
+    const int i = q0 + qi;
+    if (i < p.Lq) p.out[((size_t)n * p.Lq + i) * p.ldo + h * HD + d] = ((a0 + a1) + (a2 + a3)) / ssum[qi];
+  }
+}
+
+template <int HD>
+size_t attn_tile_lds_bytes(int Lk) {
+  constexpr int QT = 256 / HD;
+  return ((size_t)QT * (Lk + 1) + (size_t)Lk * HD + QT * HD + QT) * sizeof(float);
+}
+constexpr size_t ATTN_TILE_LDS_MAX = 150 * 1024;   // of the 160 KB per CU
 
 // in-place LayerNorm of rows [R][D]; grid ceil(R / 4), block 256 (one wave per row)
 __global__ __launch_bounds__(256) void km_layernorm(float* x, int R, int D, const float* g, const float* b) {
@@ -344,6 +533,12 @@ int ribm_create(const ribm_config* cfg, int device, ribm_handle** out) {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = fmt("hipSetDevice(%d): %s", device, hipGetErrorString(e)); delete h; return RIBM_ERR_HIP; }
   }
+  if (device >= 0) {   // score tiles above the default 64 KB of dynamic LDS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&km_attention_tile<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_TILE_LDS_MAX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&km_attention_tile<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_TILE_LDS_MAX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&km_attention_tile<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_TILE_LDS_MAX);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&km_attention_tile<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_TILE_LDS_MAX);
+  }
   *out = h;
   return RIBM_OK;
 }
@@ -452,28 +647,39 @@ int ribm_forward(ribm_handle* h, int N, int L, int rate, const float* src, const
     p.wt = h->d_blob + wt.off + col0; p.ldw = (int)wt.dims[0];
     p.bias = T(bname) + col0; p.Nout = Nout; p.act = act;
     p.res = res; p.rs = rs; p.y = y; p.ys = ys; p.L = L; p.R = R;
-    if (pos && pos_cols < Nout && pos_cols % 128 != 0) {
-      // a 128-column block must not straddle the pos / no-pos boundary: two launches
+    if (pos && pos_cols < Nout && pos_cols % TN != 0) {
+      // a TN-column block must not straddle the pos / no-pos boundary: two launches
       LinParams a = p; a.Nout = pos_cols;
-      hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (a.Nout + 127) / 128), dim3(128), 0, st, a);
+      hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (a.Nout + TN - 1) / TN), dim3(256), 0, st, a);
       LinParams b = p; b.pos = nullptr; b.wt += pos_cols; b.bias += pos_cols; b.Nout = Nout - pos_cols; b.y = y + (size_t)pos_cols * ys.k;
-      hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (b.Nout + 127) / 128), dim3(128), 0, st, b);
+      hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (b.Nout + TN - 1) / TN), dim3(256), 0, st, b);
       launches += 2;
       return;
     }
-    hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (Nout + 127) / 128), dim3(128), 0, st, p);
+    hipLaunchKernelGGL(km_linear, dim3((R + TM - 1) / TM, (Nout + TN - 1) / TN), dim3(256), 0, st, p);
     ++launches;
   };
   auto attention = [&](const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const uint8_t* kpm, int diag, float* out) {
     AttnParams p;
     p.q = q; p.ldq = ldq; p.k = k; p.ldk = ldk; p.v = v; p.ldv = ldv; p.kpm = kpm; p.diag = diag; p.out = out; p.ldo = D;
     p.Lq = L; p.Lk = L; p.scale = sqrtf(1.0f / (float)HD);
-    const dim3 grid((L + 63) / 64, H, N);
+    ++launches;
+    const size_t lds = HD == 8 ? attn_tile_lds_bytes<8>(L) : HD == 16 ? attn_tile_lds_bytes<16>(L) : HD == 32 ? attn_tile_lds_bytes<32>(L)
+                                                                                                              : attn_tile_lds_bytes<64>(L);
+    if (lds <= ATTN_TILE_LDS_MAX && !getenv("RIBM_NO_TILE_ATTENTION")) {
+      const int QT = 256 / HD;
+      const dim3 grid((L + QT - 1) / QT, H, N);
+      if (HD == 8) hipLaunchKernelGGL(km_attention_tile<8>, grid, dim3(256), lds, st, p);
+      else if (HD == 16) hipLaunchKernelGGL(km_attention_tile<16>, grid, dim3(256), lds, st, p);
+      else if (HD == 32) hipLaunchKernelGGL(km_attention_tile<32>, grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL(km_attention_tile<64>, grid, dim3(256), lds, st, p);
+      return;
+    }
+    const dim3 grid((L + 63) / 64, H, N);   // long clips: thread-per-query kernel, keys streamed through LDS
     if (HD == 8) hipLaunchKernelGGL(km_attention<8>, grid, dim3(64), 0, st, p);
     else if (HD == 16) hipLaunchKernelGGL(km_attention<16>, grid, dim3(64), 0, st, p);
     else if (HD == 32) hipLaunchKernelGGL(km_attention<32>, grid, dim3(64), 0, st, p);
     else hipLaunchKernelGGL(km_attention<64>, grid, dim3(64), 0, st, p);
-    ++launches;
   };
   auto layernorm = [&](float* x, const std::string& name) {
     hipLaunchKernelGGL(km_layernorm, dim3((R + 3) / 4), dim3(256), 0, st, x, R, D, T(name + ".weight"), T(name + ".bias"));

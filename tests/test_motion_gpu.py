@@ -59,6 +59,7 @@ def test_hip_transformer_matches_reference_outputs(name):
     (dict(hidden_dim=256, pos_hidden_dim=256, nheads=4, dim_feedforward=1024, enc_layers=1, dec_layers=2, activation="gelu"), 1, 9, 8),  # head_dim 64, widest FFN
     (dict(hidden_dim=64, pos_hidden_dim=64, nheads=8, dim_feedforward=64, enc_layers=2, dec_layers=2, pre_norm=False, activation="relu"), 3, 17, 4),  # head_dim 8, post-norm
     (dict(input_joints=6, two_stage=False), 1, 4, 8),
+    (dict(enc_layers=1, dec_layers=1), 1, 176, 8),                             # 1401 frames: score tile exceeds LDS, streamed-key attention kernel
 ])
 def test_hip_transformer_matches_oracle_on_config_variants(over, N, n_key, rate):
     spec = MotionSpec(**over)
@@ -77,6 +78,18 @@ def test_hip_transformer_matches_oracle_on_config_variants(over, N, n_key, rate)
     dj, dr = float((joints.cpu() - oj).abs().max()), float((reco.cpu() - orc).abs().max())
     print("variant %s N=%d L=%d: joints %.2e reco %.2e" % (over, N, src.shape[-1], dj, dr))
     assert dj <= TOL and dr <= TOL
+
+
+def test_streamed_key_attention_kernel_agrees_with_the_tiled_one(monkeypatch):
+    spec = MotionSpec(enc_layers=2, dec_layers=2)
+    model, T, sd = build(spec, 8)
+    P = model.PositionEmbeddingSine1D(64)
+    src, tgt, sm, tm = [t.unsqueeze(0) for t in synth.make_clip(spec, 12, 8, 3)]
+    j1, r1 = T(src, sm, P(sm), tgt, tm, P(tm), 8)
+    monkeypatch.setenv("RIBM_NO_TILE_ATTENTION", "1")
+    j2, r2 = T(src, sm, P(sm), tgt, tm, P(tm), 8)
+    torch.cuda.synchronize()
+    assert float((j1 - j2).abs().max()) <= 2e-5 and float((r1 - r2).abs().max()) <= 2e-5
 
 
 def test_interpolation_between_key_frames_is_bit_exact_and_deterministic():
