@@ -1034,6 +1034,84 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_small: 3x3 stride-1 convolution with 1..4 output channels (the RGB head conv_img 16 -> 3 and
+// the mask head conv_mask.0 32 -> 1, PGNR/models/generator.py:114-116,482-485), on the vector ALUs.
+// On the matrix cores these layers pad N to 16 columns for 1 or 3 real ones (25.5 / 32.6 us at 512x512,
+// 5 .. 9 TFLOP/s "achieved"); they are really HBM-bound reads of a 16 / 32-channel map.  A workgroup
+// stages the 18 x 18 halo of a 16 x 16 pixel tile (all input channels, prologue applied once per
+// element) and the CO x 9 x Cin filter in LDS; thread = pixel; filter reads are LDS broadcasts.
+// Uses IgemmParams (x, prologue, w [CoutPad][9][Cin], bias, y / y_nchw, act); grid (tiles, 1, B).
+// ---------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+  const int Cin = p.Cin, CK = Cin + 4, C4 = Cin / 4;
+  float* sA = smem_dyn;                       // [18 * 18][CK]
+  float* sW = smem_dyn + 18 * 18 * CK;        // [CO][9][Cin]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z;
+  const int tile = p.xcd_chunk ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ty0 = (tile / p.tilesX) * 16, tx0 = (tile % p.tilesX) * 16;
+  const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
+  for (int i = tid; i < CO * 9 * C4; i += 256)
+    *reinterpret_cast<float4*>(sW + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);   // rows 0..CO-1 are contiguous
+  const int total4 = 18 * 18 * C4;
+  for (int base = 0; base < total4; base += 256 * 8) {   // batches of independent loads
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      const int pix = idx / C4, c4 = idx - pix * C4;
+      const int iy = ty0 - 1 + pix / 18, ix = tx0 - 1 + pix % 18;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+        v[u] = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
+        if (p.pro_scale) {
+          const float4 sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+          const float4 sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+          v[u] = make_float4(v[u].x * sc.x + sh.x, v[u].y * sc.y + sh.y, v[u].z * sc.z + sh.z, v[u].w * sc.w + sh.w);
+        }
+        if (p.pro_lrelu) v[u] = lrelu4(v[u]);      // zero padding is applied after the prologue (out-of-range stays 0)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < total4) { const int pix = idx / C4, c4 = idx - pix * C4; *reinterpret_cast<float4*>(sA + pix * CK + c4 * 4) = v[u]; }
+    }
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* a = sA + ((ly + tap / 3) * 18 + lx + tap % 3) * CK;
+    const float* w = sW + tap * Cin;
+    for (int c = 0; c < Cin; c += 4) {
+      const float4 av = *reinterpret_cast<const float4*>(a + c);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + co * 9 * Cin + c);
+        acc[co] = fmaf(av.x, wv.x, acc[co]); acc[co] = fmaf(av.y, wv.y, acc[co]);
+        acc[co] = fmaf(av.z, wv.z, acc[co]); acc[co] = fmaf(av.w, wv.w, acc[co]);
+      }
+    }
+  }
+  const int oy = ty0 + ly, ox = tx0 + lx;
+  if (oy >= p.Hout || ox >= p.Wout) return;
+  const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    const float v = apply_act(acc[co] + p.bias[co], p.act);
+    p.y[pix * p.yC + p.yoff + co] = v;
+    if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
+  }
+  for (int co = CO; co < p.Cout; ++co) p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);   // channel padding, as k_igemm stores it
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_pack: concatenate up to 3 NCHW sources along channels into one zero-padded NHWC tensor
 // (torch.cat at PGNR/models/generator.py:197,232 and the NCHW->NHWC boundary conversion).
 // 64 pixels per 256-thread block; grid (ceil(HW/64), B); dC <= 32.

@@ -357,6 +357,7 @@ struct Op {
   int record_ev = -1;         // plan event recorded on its stream after it launches
   // igemm
   const Variant* var = nullptr;
+  int small_co = 0;   // > 0: direct vector-ALU convolution k_conv_small<small_co> instead of the matrix-core kernel
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
   // split-K epilogue
@@ -642,6 +643,20 @@ struct Builder {
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
+    // heads with 1..4 output channels (conv_img, conv_mask.0): direct convolution on the vector ALUs; the
+    // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
+    const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
+                       c.cinp <= 64 && !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
+    if (small) {
+      op.small_co = c.cout;
+      p.ksplit = 1;
+      p.tilesX = (Wout + 15) / 16; p.tilesY = (Hout + 15) / 16; p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+      op.grid = dim3(p.tilesX * p.tilesY, 1, B);
+      op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B;
+      P->flops[RIB_KC_IGEMM] += op.flops;
+      push(op);
+      return true;
+    }
     int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
     op.grid = dim3(tiles, v->NF == 0 ? 1 : (c.coutp + v->BN() - 1) / v->BN(), B * S);
@@ -1086,6 +1101,15 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
+        if (op.small_co > 0) {
+          const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
+          switch (op.small_co) {
+            case 1: hipLaunchKernelGGL(k_conv_small<1>, op.grid, dim3(256), lds, st, p); break;
+            case 2: hipLaunchKernelGGL(k_conv_small<2>, op.grid, dim3(256), lds, st, p); break;
+            case 3: hipLaunchKernelGGL(k_conv_small<3>, op.grid, dim3(256), lds, st, p); break;
+            default: hipLaunchKernelGGL(k_conv_small<4>, op.grid, dim3(256), lds, st, p); break;
+          }
+        } else
         hipLaunchKernelGGL(pick_igemm_fn(op.var, p), op.grid, dim3(256 * op.var->KW), 0, st, p);
       } break;
       case OP_FINALIZE: {
@@ -1599,7 +1623,10 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   Plan* P = get_plan(h, B, H, W);
   if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
   const Op& op = P->ops[idx];
-  if (op.kind == OP_IGEMM)
+  if (op.kind == OP_IGEMM && op.small_co > 0)
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|direct 16x16 tile, %d output channels on the vector ALUs|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.small_co, op.flops);
+  else if (op.kind == OP_IGEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB, op.flops);
   else
