@@ -169,7 +169,11 @@ def main():
         with open(tp) as f:
             traffic = json.load(f)["classes"]["igemm"]["hbm_bytes_per_launch"]
     roofline = {
-        "bound": "mfma", "kernel": "k_igemm (fp32 MFMA implicit-GEMM convolution, %d launches/step)" % int(prof["igemm"]["launches"] / nprof),
+        "bound": "mfma",
+        # the convolution class: k_igemm on the matrix cores; at fp32 the 1..4-channel heads (conv_img, conv_mask.0:
+        # 2 launches, 0.5 GFLOP) run as k_conv_small on the vector ALUs.  "algorithmic" = nine-tap 2*MAC count of
+        # SURVEY 8(d); the three upsample convolutions execute 4/9 of theirs (phase decomposition)
+        "kernel": "convolution class: k_igemm, fp32 MFMA implicit GEMM (%d launches/step incl. 2 k_conv_small heads)" % int(prof["igemm"]["launches"] / nprof),
         "achieved": conv_tflops, "peak": PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": conv_tflops / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
         "avg_launch_us": conv_ms * 1e3 / max(1.0, prof["igemm"]["launches"] / nprof),
