@@ -415,3 +415,36 @@ def test_every_kernel_variant_is_correct_wherever_it_fits():
                 assert e < 5e-5, (name, list(g12), ks, e)
         assert lib.rib_set_choice(h, B, H, W, name.encode(), -1, 1) == 0
     assert accepted > 150 and seen_kw > 10 and seen_tb > 10, (tried, accepted, seen_kw, seen_tb)
+
+
+def test_direct_head_convolutions_agree_with_the_matrix_core_path(monkeypatch):
+    """conv_img (16 -> 3) and conv_mask.0 (32 -> 1) run as k_conv_small on the vector ALUs; with
+    RIB_NO_SMALLCONV they go through k_igemm's 16-column path.  Same frame either way, at an odd size too."""
+    spec, sd, _ = build("full", 0)
+    for (H, W, seed) in ((64, 64, 1), (48, 80, 2), (256, 256, 3)):
+        label, fake, prev = synth.make_inputs(spec, 1, H, W, seed)
+        monkeypatch.delenv("RIB_NO_SMALLCONV", raising=False)
+        G1 = rib.Generator(rib.hsm_gen_config()).eval(); G1.load_state_dict(sd)
+        i1, m1 = [t.clone() for t in G1(label, None, fake, prev)]
+        n1 = G1._lib.rib_num_launches(G1._h, 1, H, W)
+        monkeypatch.setenv("RIB_NO_SMALLCONV", "1")
+        G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
+        i2, m2 = G2(label, None, fake, prev)
+        torch.cuda.synchronize()
+        assert n1 == G2._lib.rib_num_launches(G2._h, 1, H, W)
+        e = max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max()))
+        assert e < 2e-6, (H, W, e)
+        del G1, G2
+
+
+def test_upsample_convolutions_as_phase_convolutions_match_oracle_at_odd_sizes():
+    """The mask network's Upsample(2) -> 3x3 convolutions run as four 2x2 phase convolutions of the
+    half-resolution map (4/9 of the MACs, filters summed at fold time).  Sizes whose source maps do not
+    tile evenly (H/8 not a multiple of the 8 / 16-pixel tiles) exercise the tile borders."""
+    spec, sd, G = build("full", 0)
+    R = oracle(spec, sd)
+    for (B, H, W, seed) in ((1, 48, 80, 5), (2, 80, 48, 6), (1, 176, 112, 7)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        img, mask = G(label, None, fake, prev)
+        ri, rm = R(label, None, fake, prev)
+        assert float((img.cpu() - ri).abs().max()) < TOL and float((mask.cpu() - rm).abs().max()) < TOL, (B, H, W)
