@@ -779,17 +779,17 @@ __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p)
       a2 += (double)base[(size_t)t * 2 * p.Cs + p.Cs + c];
     }
   }
-  red[0][sl][cl] = a1;
-  red[1][sl][cl] = a2;
+  // fixed-shape reduction over the 64 slices: the 4 slices of a wavefront with shuffles, then the 16
+  // wavefront sums in order by one thread per channel (one barrier; an LDS tree needed seven)
+  a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+  a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+  if ((threadIdx.x & 63) < 16) { red[0][threadIdx.x >> 6][cl] = a1; red[1][threadIdx.x >> 6][cl] = a2; }
   __syncthreads();
-  // fixed-shape tree over the 64 slices (a serial walk by one thread costs 128 dependent LDS reads)
+  if (sl == 0) {
+    double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    if (sl < s) {
-      red[0][sl][cl] += red[0][sl + s][cl];
-      red[1][sl][cl] += red[1][sl + s][cl];
-    }
-    __syncthreads();
+    for (int w = 0; w < 16; ++w) { t1 += red[0][w][cl]; t2 += red[1][w][cl]; }
+    red[0][0][cl] = t1; red[1][0][cl] = t2;
   }
   if (sl == 0 && c < p.C) {
     const double s1 = red[0][0][cl], s2 = red[1][0][cl];
@@ -831,16 +831,47 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
   const size_t sstride = (size_t)p.B * npix * p.CoutPad;
   const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  // all slab reads of the block's four pixel rounds are issued before the first add: one memory round trip
+  // for split factors <= 4 (a load -> add loop per pixel paid one per pixel and per four slabs); the slabs are
+  // still added in the fixed order 0, 1, 2, ...
+  float4 acc4[4];
+  {
+    float4 v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = blockIdx.x * ppb + k * slots + slot;
+      const float* src = p.slab + ((size_t)n * npix + (pix < npix ? pix : 0)) * p.CoutPad + c4 * 4;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[k][s] = s < p.ksplit ? *reinterpret_cast<const float4*>(src + s * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 a = v[k][0];
+#pragma unroll
+      for (int s = 1; s < 4; ++s)
+        if (s < p.ksplit) { a.x += v[k][s].x; a.y += v[k][s].y; a.z += v[k][s].z; a.w += v[k][s].w; }
+      acc4[k] = a;
+    }
+    for (int s0 = 4; s0 < p.ksplit; s0 += 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pix = blockIdx.x * ppb + k * slots + slot;
+        const float* src = p.slab + ((size_t)n * npix + (pix < npix ? pix : 0)) * p.CoutPad + c4 * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[k][s] = s0 + s < p.ksplit ? *reinterpret_cast<const float4*>(src + (s0 + s) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (s0 + s < p.ksplit) { acc4[k].x += v[k][s].x; acc4[k].y += v[k][s].y; acc4[k].z += v[k][s].z; acc4[k].w += v[k][s].w; }
+    }
+  }
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int pix = blockIdx.x * ppb + k * slots + slot;
     if (pix < npix) {
-      const float* src = p.slab + ((size_t)n * npix + pix) * p.CoutPad + c4 * 4;
-      float4 a = *reinterpret_cast<const float4*>(src);
-#pragma unroll 4
-      for (int s = 1; s < p.ksplit; ++s) {
-        const float4 t = *reinterpret_cast<const float4*>(src + s * sstride);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-      }
+      float4 a = acc4[k];
       a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
       float v[4] = {a.x, a.y, a.z, a.w};
       const int oy = pix / p.Wout, ox = pix % p.Wout;
@@ -962,19 +993,20 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
     const int pix = blockIdx.x * ppb + k * slots + slot;
     if (pix < npix && slot < slots) {
       const int oy = pix / Wo, ox = pix % Wo;
+      // the nine taps are loaded unconditionally from clamped coordinates (one batch of independent loads)
+      // and masked when added: same sum, same order as skipping the out-of-range taps
+      float4 v[9]; float m[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy * 2 - 1 + t / 3, ix = ox * 2 - 1 + t % 3;
+        m[t] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        v[t] = *reinterpret_cast<const float4*>(xn + ((size_t)cy * p.W + cx) * p.C + c4 * 4);
+      }
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int iy = oy * 2 - 1 + dy;
-        if (iy < 0 || iy >= p.H) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int ix = ox * 2 - 1 + dx;
-          if (ix < 0 || ix >= p.W) continue;
-          const float4 v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * p.W + ix) * p.C + c4 * 4);
-          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
-      }
+      for (int t = 0; t < 9; ++t)
+        if (m[t] != 0.f) { a.x += v[t].x; a.y += v[t].y; a.z += v[t].z; a.w += v[t].w; }
       const float inv9 = 1.f / 9.f;
       a.x *= inv9; a.y *= inv9; a.z *= inv9; a.w *= inv9;
       *reinterpret_cast<float4*>(p.y + ((size_t)n * npix + pix) * p.C + c4 * 4) = a;
