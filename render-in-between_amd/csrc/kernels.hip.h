@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB> G;
   static_assert(TB == 1 || (TB == 3 && KS == 3), "filter slices per barrier: one tap, or one row of a 3x3 filter");
   constexpr int NT = G::NT;
-  static_assert(KW == 1 || (!BF16 && NF > 0 && !SPADE && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column conv path, BK/8 divisible by KW");
+  static_assert(KW == 1 || (!BF16 && NF > 0 && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column path (conv or SPADE), BK/8 divisible by KW");
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");

@@ -190,6 +190,10 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3>, 1, 3}
 #define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
+// RIB_VSK: in-workgroup split-K twin of a SPADE geometry: the fused kernel on the small deep maps with 8 / 16 waves
+// per tile instead of the unfused pair (split-K GEMM into slabs + k_spade_modulate)
+#define RIB_VSK(FRW, WM, WN, MF, NF, BK, KW) \
+  Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW}
 #define RIB_VB(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true}
 
@@ -246,6 +250,8 @@ const Variant kVariants[] = {
     RIB_VK(8, 2, 2, 1, 1, 16, 2, 3, false, 2),  RIB_VK(16, 4, 1, 1, 1, 16, 2, 3, false, 2),
     RIB_VK(16, 4, 1, 1, 1, 32, 1, 1, false, 2), RIB_VK(16, 4, 1, 1, 2, 32, 1, 1, false, 2),
     RIB_VK(16, 4, 1, 1, 2, 64, 1, 1, false, 2), RIB_VK(8, 2, 2, 1, 1, 64, 1, 1, false, 2),
+    RIB_VSK(16, 4, 1, 1, 2, 64, 2), RIB_VSK(16, 4, 1, 1, 2, 64, 4), RIB_VSK(8, 2, 2, 1, 2, 64, 2), RIB_VSK(8, 2, 2, 1, 2, 64, 4),
+    RIB_VSK(16, 4, 1, 1, 2, 32, 2), RIB_VSK(16, 4, 1, 1, 2, 32, 4),
     // ---- three-taps-per-barrier twins for launches with LDS to spare (<= 2 workgroups per CU) ----
     RIB_VT(16, 4, 1, 1, 1, 32, 1, false), RIB_VT(16, 4, 1, 1, 2, 32, 1, false), RIB_VT(16, 4, 1, 2, 1, 32, 1, false),
     RIB_VT(8, 2, 2, 1, 1, 32, 1, false),  RIB_VT(16, 4, 1, 1, 1, 16, 1, false), RIB_VT(16, 4, 1, 1, 2, 16, 1, false),
