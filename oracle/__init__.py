@@ -1,12 +1,17 @@
 """TEST INFRASTRUCTURE — not part of the product.
 
-CPU restatement (PyTorch fp32 functional ops, NCHW) of the reference's
-pose-guided generator forward pass and of the autoregressive driver step.
-Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
-``cpu_baseline`` leg may import this package, and only as the checker.
+CPU restatements of the reference's algorithms on the scoped path:
+  generator_ref   PyTorch fp32 functional ops, NCHW: the pose-guided generator forward and the
+                  autoregressive driver step (rows a-1 .. a-14)
+  rasterise_ref   numpy / scipy: the label-map rasterisation (row f-2)
+  motion_ref      PyTorch fp32 + numpy: stage 1, the motion transformer and its OpenPose json plumbing (row f-4)
+  ref_import      loader of the REAL reference generator (build container only; used by the golden scripts)
+Only ``tests/``, ``__graft_entry__.smoke()``, ``bench.py``'s ``cpu_baseline`` leg and the CPU-baseline legs of
+the measurement scripts under ``tools/`` may import this package, and only as the checker / the CPU side
+of a comparison; nothing under ``render-in-between_amd/`` does.
 
-Parity pin: validated in the build container against the *imported reference
-generator itself* (``oracle/ref_import.py``; see tests/golden/make_golden.py),
-whose outputs are committed as fixtures under tests/golden/.  The reference
-has no tests or golden vectors of its own for this path.
+Parity pin: each restatement is validated in the build container against the *imported reference
+itself* (tests/golden/make_golden.py, make_golden_raster.py, make_golden_motion.py), whose outputs are
+committed as fixtures under tests/golden/.  The reference has no tests or golden vectors of its own
+for these paths.
 """
