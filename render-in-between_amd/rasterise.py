@@ -163,7 +163,12 @@ def frame_tables(landmarks, conf, height, width, thres1=0.001, thres2=0.001):
 def rasterise_labels(gen, frames, height, width, sigma=5, thres1=0.001, thres2=0.001):
     """frames: list of (landmarks, conf) already scaled to the model size.
     -> [T, 22, H, W] fp32 CUDA tensor, drawn by the GPU (gen.rasterise -> rib_rasterise)."""
-    tabs = [frame_tables(lm, cf, height, width, thres1, thres2) for lm, cf in frames]
+    return rasterise_tables(gen, [frame_tables(lm, cf, height, width, thres1, thres2) for lm, cf in frames], height, width, sigma)
+
+
+def rasterise_tables(gen, tabs, height, width, sigma=5):
+    """Same, from per-frame host tables already built (frame_tables): the driver builds them in its
+    decode workers so that the 0.8 ms/frame of host work overlaps the GPU."""
     strokes = np.stack([t[0] for t in tabs])
     peaks = np.stack([t[1] for t in tabs])
     w, radius = gaussian_weights(sigma)
