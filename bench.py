@@ -188,7 +188,7 @@ def main():
     # ---- parity on the bench inputs + CPU baseline (oracle timed on the host cores) ----
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and args.mode == "frame":
+    if not args.no_cpu_baseline and args.mode == "frame" and world == 1:   # rank 0 at N=1 only
         from oracle import generator_ref
         R = generator_ref.RefGenerator(spec, sd)
         torch.set_num_threads(min(16, os.cpu_count() or 1))   # 16 threads is the fastest setting on the 256-CPU GPU box (tools/cpu_threads.py sweep: 8/16/32/64/128)
@@ -210,13 +210,14 @@ def main():
                "sample": "%d forward+blend passes of the same %dx%d B=%d fp32 workload through the CPU oracle "
                          "(PyTorch restatement validated against the imported reference), median" % (args.cpu_frames, H, W, B)}
 
+    dt_name = "fp32" if args.dtype == "f32" else "bf16 matrix-core operands (fp32 accumulate / statistics / storage)"
     line = {
         "metric": "rendered frames/sec at 512x512 (generator forward + blend, device-resident)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("%dx%d single-frame generator fwd + blend, batch=%d, fp32" % (H, W, B) if args.mode == "frame" else
-                                "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, fp32" % (H, W, args.frames, B))
+        "config": {"workload": ("%dx%d single-frame generator fwd + blend, batch=%d, %s" % (H, W, B, dt_name) if args.mode == "frame" else
+                                "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, %s" % (H, W, args.frames, B, dt_name))
                                + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
                    "frames_per_step_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), one RCCL weight broadcast" % world,
                    "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1,
