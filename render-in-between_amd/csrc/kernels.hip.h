@@ -650,24 +650,72 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
+        // the 16 residual reads of a fragment are issued as one batch from clamped (always valid) addresses: inside
+        // the bounds-checked store loop below each read sat behind the previous element's store (the compiler
+        // cannot reorder a load over a possibly aliasing store): 16 serialised memory round trips per fragment
+        float rv[16];
+        if (p.res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+            int ox = tx0 + row % FRW;
+            if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
+            oy = min(oy, p.Hout - 1); ox = min(ox, p.Wout - 1);
+            const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)
+                                          : ((size_t)n * p.Hout + oy) * p.Wout + ox;
+            rv[r] = p.res[rpix * p.resC + min(col, p.resC - 1)];
+          }
+        }
+        // values first (no memory operations, the activation chosen once per fragment), then the stores: with
+        // loads, uniform branches and stores interleaved per element the compiler waited for vmcnt(0) - i.e. for
+        // the previous element's STORE to be acknowledged - before every element (16 serialised round trips)
+        float vv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = acc[ph * MF + mf][nf][r] + bv;
+        if (p.res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] += rv[r];
+        }
+        if (p.act == ACT_LRELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] = lrelu(vv[r]);
+        } else if (p.act == ACT_TANH) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] = tanhf(vv[r]);
+        } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] = 1.f / (1.f + __expf(-vv[r]));
+        }
+        unsigned okm = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
           int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
           int ox = tx0 + row % FRW;
           if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }   // phase ph of source pixel (oy, ox)
-          if (cvalid && oy < p.Hout && ox < p.Wout) {
-            const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
-            float v = acc[ph * MF + mf][nf][r] + bv;
-            if (p.res) {
-              const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : pix;
-              v += p.res[rpix * p.resC + col];
-            }
-            v = apply_act(v, p.act);
-            p.y[pix * p.yC + p.yoff + col] = v;
-            if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = v;
-            s1[nf] += v;
-            s2[nf] += v * v;
+          const bool ok = cvalid && oy < p.Hout && ox < p.Wout;
+          okm |= ok ? (1u << r) : 0u;
+          const float v = ok ? vv[r] : 0.f;      // adding 0 leaves the partial sums unchanged
+          s1[nf] += v;
+          s2[nf] += v * v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          int ox = tx0 + row % FRW;
+          if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
+          if (okm & (1u << r)) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + col] = vv[r];
+        }
+        if (p.y_nchw) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+            int ox = tx0 + row % FRW;
+            if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
+            if (okm & (1u << r)) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = vv[r];
           }
         }
       }
@@ -717,14 +765,24 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
+        // all 16 reads of the normalised tensor first (clamped, always valid addresses), then the modulation and
+        // the stores: one memory round trip per fragment instead of 16 serialised load -> store pairs
+        float xr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
+          const int ox = min(tx0 + row % FRW, p.Wout - 1);
+          const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+          xr[r] = (RIB_EXP & 8) ? 1.f : p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0)];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
           const int ox = tx0 + row % FRW;
           if (vvalid && oy < p.Hout && ox < p.Wout) {
-            const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-            const float xv = (RIB_EXP & 8) ? 1.f : p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c];
+            const float xv = xr[r];
             const float gamma = acc[mf][2 * q][r] + bg;
             const float beta = acc[mf][2 * q + 1][r] + bb;
             float o = (xv * sc + sh) * (1.f + gamma) + beta;
