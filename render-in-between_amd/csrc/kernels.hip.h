@@ -925,29 +925,43 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
           if (s0 + s < p.ksplit) { acc4[k].x += v[k][s].x; acc4[k].y += v[k][s].y; acc4[k].z += v[k][s].z; acc4[k].w += v[k][s].w; }
     }
   }
+  // residual reads of the four pixel rounds as one batch (clamped addresses), then values, then the stores: a
+  // read inside the store loop waits for the previous store's acknowledgement (see k_igemm's epilogue)
+  float rres[4][4];
+  if (p.res) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = min(blockIdx.x * ppb + k * slots + slot, npix - 1);
+      const int oy = pix / p.Wout, ox = pix % p.Wout;
+      const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : (size_t)n * npix + pix;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rres[k][e] = p.res[rpix * p.resC + min(c4 * 4 + e, p.resC - 1)];
+    }
+  }
+  float vals[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pix = blockIdx.x * ppb + k * slots + slot;
+    const float4 a = acc4[k];
+    const float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if (p.res) t += rres[k][e];
+      t = apply_act(t, p.act);
+      vals[k][e] = (pix < npix && c4 * 4 + e < p.Cout) ? t : 0.f;
+    }
+    s1.x += vals[k][0]; s1.y += vals[k][1]; s1.z += vals[k][2]; s1.w += vals[k][3];
+    s2.x += vals[k][0] * vals[k][0]; s2.y += vals[k][1] * vals[k][1]; s2.z += vals[k][2] * vals[k][2]; s2.w += vals[k][3] * vals[k][3];
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int pix = blockIdx.x * ppb + k * slots + slot;
     if (pix < npix) {
-      float4 a = acc4[k];
-      a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
-      float v[4] = {a.x, a.y, a.z, a.w};
-      const int oy = pix / p.Wout, ox = pix % p.Wout;
       const size_t opix = (size_t)n * npix + pix;
-      const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : opix;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int col = c4 * 4 + e;
-        if (col < p.Cout) {
-          float t = v[e];
-          if (p.res) t += p.res[rpix * p.resC + col];
-          t = apply_act(t, p.act);
-          p.y[opix * p.yC + p.yoff + col] = t;
-          v[e] = t;
-        } else v[e] = 0.f;
-      }
-      s1.x += v[0]; s1.y += v[1]; s1.z += v[2]; s1.w += v[3];
-      s2.x += v[0] * v[0]; s2.y += v[1] * v[1]; s2.z += v[2] * v[2]; s2.w += v[3] * v[3];
+      for (int e = 0; e < 4; ++e)
+        if (c4 * 4 + e < p.Cout) p.y[opix * p.yC + p.yoff + c4 * 4 + e] = vals[k][e];
     }
   }
   if (p.stat_part) {
