@@ -1160,28 +1160,37 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
   for (int i = tid; i < CO * 9 * C4; i += 256)
     *reinterpret_cast<float4*>(sW + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);   // rows 0..CO-1 are contiguous
   const int total4 = 18 * 18 * C4;
-  for (int base = 0; base < total4; base += 256 * 8) {   // batches of independent loads
+  // a thread keeps one channel group across its staging slots (256 % C4 == 0): prologue constants loaded once
+  const int c4 = tid % C4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.pro_scale) {
+    sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+    sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+  }
+  float bias[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) bias[co] = p.bias[co];
+  for (int base = 0; base < total4; base += 256 * 8) {
+    // one batch of UNCONDITIONAL loads from clamped coordinates (a per-element `if (in range) load` is control flow,
+    // after which the compiler waits for vmcnt(0) per element: eight serialised round trips), then the prologue
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256 + tid;
-      const int pix = idx / C4, c4 = idx - pix * C4;
-      const int iy = ty0 - 1 + pix / 18, ix = tx0 - 1 + pix % 18;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
-        v[u] = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
-        if (p.pro_scale) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
-          const float4 sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
-          v[u] = make_float4(v[u].x * sc.x + sh.x, v[u].y * sc.y + sh.y, v[u].z * sc.z + sh.z, v[u].w * sc.w + sh.w);
-        }
-        if (p.pro_lrelu) v[u] = lrelu4(v[u]);      // zero padding is applied after the prologue (out-of-range stays 0)
-      }
+      const int idx = min(base + u * 256 + tid, total4 - 1);
+      const int pix = idx / C4;
+      const int iy = min(max(ty0 - 1 + pix / 18, 0), p.Hin - 1), ix = min(max(tx0 - 1 + pix % 18, 0), p.Win - 1);
+      v[u] = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = base + u * 256 + tid;
-      if (idx < total4) { const int pix = idx / C4, c4 = idx - pix * C4; *reinterpret_cast<float4*>(sA + pix * CK + c4 * 4) = v[u]; }
+      const int pix = idx / C4;
+      const int iy = ty0 - 1 + pix / 18, ix = tx0 - 1 + pix % 18;
+      float4 t = v[u];
+      if (p.pro_scale) t = make_float4(t.x * sc.x + sh.x, t.y * sc.y + sh.y, t.z * sc.z + sh.z, t.w * sc.w + sh.w);
+      if (p.pro_lrelu) t = lrelu4(t);
+      if (!(iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)) t = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+      if (idx < total4) *reinterpret_cast<float4*>(sA + pix * CK + c4 * 4) = t;
     }
   }
   __syncthreads();
@@ -1208,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
   const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
-    const float v = apply_act(acc[co] + p.bias[co], p.act);
+    const float v = apply_act(acc[co] + bias[co], p.act);
     p.y[pix * p.yC + p.yoff + co] = v;
     if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
   }
