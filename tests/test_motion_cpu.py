@@ -196,3 +196,15 @@ def test_motion_model_refuses_to_run_without_gpu():
     from render_in_between_amd.motion import model
     with pytest.raises(RuntimeError):
         model.MotionTransformer(MotionSpec())
+
+
+def test_oracle_prediction_depends_on_key_frames_only():
+    spec = MotionSpec(enc_layers=2, dec_layers=2)
+    sd = synth.make_state_dict(spec, 1)
+    src, tgt, sm, tm = [t.unsqueeze(0) for t in synth.make_clip(spec, 5, 4, 2)]
+    pos = motion_ref.position_embedding_sine(sm, spec.pos_hidden_dim // 2)
+    j1, _ = motion_ref.transformer_forward(sd, spec.as_dict(), src, sm, pos, tgt, tm, pos, 4)
+    noisy = src.clone()
+    noisy[:, :, sm[0]] = 7.0
+    j2, _ = motion_ref.transformer_forward(sd, spec.as_dict(), noisy, sm, pos, tgt, tm, pos, 4)
+    assert torch.allclose(j1, j2, atol=1e-6)

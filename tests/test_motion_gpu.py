@@ -161,3 +161,21 @@ def test_stage1_cli_on_openpose_folders_matches_reference(tmp_path, name):
     assert d.max() <= 1e-4
     lin = pose_io.openpose2motion(str(tmp_path / "out" / "Linear_motion" / "clip0"), scale=512, offset=256)[0]
     assert (np.abs(lin - z["linear"]) * (z["conf"] > 0)).max() <= 1e-12
+
+
+def test_full_length_clip_ignores_what_is_stored_at_non_key_frames():
+    """Size-independent property at the reference's full clip length (321 frames): with two_stage the prediction
+    depends on the key frames only - non-key frames are masked as attention keys and interpolate_embedding reads
+    multiples of `rate` - so garbage at the masked positions of the encoder input must not change a bit of it."""
+    spec = MotionSpec()
+    model, T, sd = build(spec, 4)
+    P = model.PositionEmbeddingSine1D(64)
+    src, tgt, sm, tm = [t.unsqueeze(0) for t in synth.make_clip(spec, 41, 8, 9)]
+    j1, r1 = T(src, sm, P(sm), tgt, tm, P(tm), 8)
+    noisy = src.clone()
+    noisy[:, :, sm[0]] = torch.randn(1, spec.input_joints, int(sm.sum())) * 10.0
+    j2, r2 = T(noisy, sm, P(sm), None, tm, P(tm), 8)
+    torch.cuda.synchronize()
+    assert torch.equal(j1, j2)
+    assert torch.equal(r1[::8], r2[::8])                   # the reconstruction at the key frames too
+    assert not torch.equal(r1, r2)                         # (elsewhere it is input + correction, so it differs)
