@@ -652,7 +652,8 @@ struct Builder {
     // heads with 1..4 output channels (conv_img, conv_mask.0): direct convolution on the vector ALUs; the
     // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
     const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
-                       c.cinp <= 64 && 256 % (c.cinp / 4) == 0 && !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
+                       c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
+                       !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
     if (small) {
       op.small_co = c.cout;
       p.ksplit = 1;
