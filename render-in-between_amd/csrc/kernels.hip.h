@@ -122,10 +122,17 @@ struct IgemmGeom {
   static constexpr int IH = UPS ? (TH + 2) : ((TH - 1) * STRIDE + KS);
   static constexpr int IW = UPS ? (TW + 2) : ((TW - 1) * STRIDE + KS);
   static constexpr int CK = BK + 4;            // padded LDS row: conflict-free ds_read_b128
+  // Stride 2: the halo tile is stored with even and odd columns de-interleaved (column x -> (x & 1) * IWH + x / 2),
+  // so that the 16 lanes of a ds_read_b128 phase, which step 2 pixels in x, read consecutive LDS pixels as in the
+  // stride-1 case (stepping 2 * CK floats they hit only half of the banks: 35-49 % of the LDS cycles of the
+  // stride-2 layers were bank conflicts, PMC SQ_LDS_BANK_CONFLICT).  8-wide fragments put two tile rows into one
+  // phase: their LDS row pitch is padded to 4 (mod 8) pixels, which moves the second row onto the other 32 banks.
+  static constexpr int IWH = (IW + 1) / 2;
+  static constexpr int IWP = (STRIDE == 2 && FRW == 8) ? ((IW + 3) / 8 * 8 + 4) : IW;   // LDS row pitch in pixels
   // NF == 0 selects the 16-column path (v_mfma_f32_16x16x4_f32) for layers with <= 16 output
   // channels: no half-empty 32-column fragments
   static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
-  static constexpr int SA = IH * IW * CK;      // floats
+  static constexpr int SA = IH * IWP * CK;     // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
   static constexpr int NB4 = (BN * BK / 4 + NT - 1) / NT; // float4 filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
@@ -321,7 +328,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         if (!raw && p.pro_lrelu) v = lrelu4(v);
       }
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + pix * G::CK + ac4 * 4) = v;
+      int lpix = pix;
+      if constexpr (STRIDE == 2) { const int ly = pix / G::IW, lx = pix % G::IW; lpix = ly * G::IWP + (lx & 1) * G::IWH + (lx >> 1); }
+      if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + lpix * G::CK + ac4 * 4) = v;
     }
   };
 
@@ -359,8 +368,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     int aoff[MF];   // LDS float offset of this lane's pixel in the (dy, dx) window
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const int r = fy[mf] * STRIDE + dy, c = fx * STRIDE + dx;
-      aoff[mf] = (r * G::IW + c) * G::CK;
+      const int r = fy[mf] * STRIDE + dy;
+      const int c = STRIDE == 2 ? (dx & 1) * G::IWH + fx + (dx >> 1) : fx * STRIDE + dx;   // stride 2: de-interleaved columns
+      aoff[mf] = (r * G::IWP + c) * G::CK;
     }
     const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
     static_assert(!BF16 || (BK % 16 == 0 && NF > 0), "bf16 matrix-core path: 16-channel steps, 32-column fragments");

@@ -163,7 +163,8 @@ struct Variant {
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
-    const int main_loop = (ih * iw * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;
+    const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
+    const int main_loop = (ih * iwp * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
   }
