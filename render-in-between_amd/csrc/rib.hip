@@ -189,6 +189,12 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, (S == 1 && !UPS), true, 1, 3>, false,               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, true, 1, 3>,                                \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3>, 1, 3}
+// RIB_VTK: three taps per barrier AND KW wave groups per tile (8 / 16 waves share the 3-slice filter buffers)
+#define RIB_VTK(FRW, WM, WN, MF, NF, BK, S, KW)                                                                         \
+  Variant{FRW, WM, WN, MF, NF, BK, S, 3, false, false,                                                                  \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 3>, false,                    \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 3>,                             \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 3>, KW, 3}
 #define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
 // RIB_VSK: in-workgroup split-K twin of a SPADE geometry: the fused kernel on the small deep maps with 8 / 16 waves
@@ -257,6 +263,9 @@ const Variant kVariants[] = {
     RIB_VT(16, 4, 1, 1, 1, 32, 1, false), RIB_VT(16, 4, 1, 1, 2, 32, 1, false), RIB_VT(16, 4, 1, 2, 1, 32, 1, false),
     RIB_VT(8, 2, 2, 1, 1, 32, 1, false),  RIB_VT(16, 4, 1, 1, 1, 16, 1, false), RIB_VT(16, 4, 1, 1, 2, 16, 1, false),
     RIB_VT(8, 2, 2, 1, 1, 32, 2, false),  RIB_VT(8, 2, 2, 1, 1, 16, 2, false),  RIB_VT(16, 4, 1, 1, 2, 16, 2, false),
+    RIB_VTK(16, 4, 1, 1, 1, 32, 1, 2), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 2), RIB_VTK(16, 4, 1, 2, 1, 32, 1, 2), RIB_VTK(8, 2, 2, 1, 1, 32, 1, 2),
+    RIB_VTK(16, 4, 1, 1, 1, 32, 1, 4), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 4),
+    RIB_VTK(8, 2, 2, 1, 1, 32, 2, 2),  RIB_VTK(16, 4, 1, 1, 2, 16, 2, 2),  RIB_VTK(8, 2, 2, 1, 1, 16, 2, 2),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
