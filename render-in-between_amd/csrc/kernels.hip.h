@@ -165,7 +165,7 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB> G;
-  static_assert(TB == 1 || (TB == 3 && KS == 3), "filter slices per barrier: one tap, or one row of a 3x3 filter");
+  static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3), "filter slices per barrier: one tap, one row of a 3x3 filter, or all nine");
   constexpr int NT = G::NT;
   static_assert(KW == 1 || (!BF16 && NF > 0 && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column path (conv or SPADE), BK/8 divisible by KW");
   constexpr bool N16 = (NF == 0);
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     }
   };
 
-  auto loadB3 = [&](int kc, int dy) {     // TB == 3: the three slices of filter row dy
+  auto loadB3 = [&](int kc, int dy) {     // TB == 3: the three slices of filter row dy; TB == 9: all nine (dy = 0)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < (TB > 1 ? TB : 3); ++t)
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
@@ -272,18 +272,18 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
           v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + (dy * 3 + t) * p.Cin + kc + c4 * 4);
-        breg[(TB == 3 ? t : 0) * G::NB4 + i] = v;
+        breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
   auto storeB3 = [&](int buf) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < (TB > 1 ? TB : 3); ++t)
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         if (row < G::BN)
-          *reinterpret_cast<float4*>(sB + (buf * 3 + t) * G::SB + row * G::CK + c4 * 4) = breg[(TB == 3 ? t : 0) * G::NB4 + i];
+          *reinterpret_cast<float4*>(sB + (buf * (TB > 1 ? TB : 3) + t) * G::SB + row * G::CK + c4 * 4) = breg[(TB > 1 ? t : 0) * G::NB4 + i];
       }
   };
 
@@ -467,6 +467,21 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         compute_tap((ph >> 1) + ((t >> 1) & 1), (ph & 1) + (t & 1), buf, ph);
       }
 #endif
+    }
+  } else if constexpr (TB == 9) {
+    // all nine filter slices of a chunk staged at once (double-buffered across chunks): one barrier pair per chunk
+    loadB3(kc_begin, 0);
+    prefetchA(kc_begin);
+    int stage = 0;
+    for (int kc = kc_begin; kc < kc_end; kc += BK, ++stage) {
+      __syncthreads();
+      writeA(false);
+      const int buf = stage & 1;
+      storeB3(buf);
+      if (kc + BK < kc_end) { loadB3(kc + BK, 0); prefetchA(kc + BK); }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 9; ++t) compute_tap(t / 3, t % 3, buf * 9 + t);
     }
   } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);

@@ -195,6 +195,12 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 3>, false,                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 3>,                             \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 3>, KW, 3}
+// RIB_V9: all nine filter slices of a chunk per barrier pair (TB = 9), optionally with KW wave groups
+#define RIB_V9(FRW, WM, WN, MF, NF, BK, S, KW)                                                                          \
+  Variant{FRW, WM, WN, MF, NF, BK, S, 3, false, false,                                                                  \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 9>, false,                    \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 9>,                             \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 9>, KW, 9}
 #define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
 // RIB_VSK: in-workgroup split-K twin of a SPADE geometry: the fused kernel on the small deep maps with 8 / 16 waves
@@ -266,6 +272,10 @@ const Variant kVariants[] = {
     RIB_VTK(16, 4, 1, 1, 1, 32, 1, 2), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 2), RIB_VTK(16, 4, 1, 2, 1, 32, 1, 2), RIB_VTK(8, 2, 2, 1, 1, 32, 1, 2),
     RIB_VTK(16, 4, 1, 1, 1, 32, 1, 4), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 4),
     RIB_VTK(8, 2, 2, 1, 1, 32, 2, 2),  RIB_VTK(16, 4, 1, 1, 2, 16, 2, 2),  RIB_VTK(8, 2, 2, 1, 1, 16, 2, 2),
+    RIB_V9(16, 4, 1, 1, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 16, 1, 2), RIB_V9(16, 4, 1, 1, 2, 16, 1, 1), RIB_V9(16, 4, 1, 1, 2, 16, 1, 2),
+    RIB_V9(16, 4, 1, 1, 1, 32, 1, 2), RIB_V9(16, 4, 1, 1, 1, 32, 1, 4), RIB_V9(8, 2, 2, 1, 1, 16, 1, 2),
+    RIB_V9(16, 4, 1, 2, 1, 16, 1, 2), RIB_V9(16, 4, 1, 2, 1, 32, 1, 2),
+    RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 2, 16, 2, 2), RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
