@@ -165,7 +165,8 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB> G;
-  static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3), "filter slices per barrier: one tap, one row of a 3x3 filter, or all nine");
+  static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS),
+                "filter slices per barrier: one tap, one row of a 3x3 filter, all nine; phase convolutions: the four taps of a phase");
   constexpr int NT = G::NT;
   static_assert(KW == 1 || (!BF16 && NF > 0 && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column path (conv or SPADE), BK/8 divisible by KW");
   constexpr bool N16 = (NF == 0);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
   static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0), "16-column path: 8x16-style tiles only");
-  static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && TB == 1 && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
+  static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && (TB == 1 || TB == 4) && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
   constexpr int PH = G::PH;
   static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + (dy * 3 + t) * p.Cin + kc + c4 * 4);
+          v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + (dy * (TB == 4 ? 4 : 3) + t) * p.Cin + kc + c4 * 4);
         breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
@@ -429,7 +430,27 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     }
   };
 
-  if constexpr (UPS) {
+  if constexpr (UPS && TB == 4) {
+    // the four taps of a phase per barrier (4 barriers per chunk instead of 16)
+    loadB3(kc_begin, 0);
+    prefetchA(kc_begin);
+    int stage = 0;
+    for (int kc = kc_begin; kc < kc_end; kc += BK) {
+      __syncthreads();
+      writeA(false);
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph, ++stage) {
+        const int buf = stage & 1;
+        storeB3(buf);
+        if (ph < 3) loadB3(kc, ph + 1);
+        else if (kc + BK < kc_end) loadB3(kc + BK, 0);
+        if (ph == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) compute_tap((ph >> 1) + (t >> 1), (ph & 1) + (t & 1), buf * 4 + t, ph);
+      }
+    }
+  } else if constexpr (UPS) {
     // 16 (phase, tap) steps per chunk, fully unrolled so that the accumulator set is a compile-time choice
     loadB(kc_begin, 0);
     prefetchA(kc_begin);

@@ -201,6 +201,12 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 9>, false,                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 9>,                             \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 9>, KW, 9}
+// RIB_VU4: phase-decomposed upsample convolution with the four taps of a phase per barrier (TB = 4)
+#define RIB_VU4(FRW, WM, WN, MF, NF, BK)                                                                                \
+  Variant{FRW, WM, WN, MF, NF, BK, 1, 3, true, false,                                                                   \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4>, false,                         \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4>,                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, false, 1, 4>, 1, 4}
 #define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
 // RIB_VSK: in-workgroup split-K twin of a SPADE geometry: the fused kernel on the small deep maps with 8 / 16 waves
@@ -275,6 +281,7 @@ const Variant kVariants[] = {
     RIB_V9(16, 4, 1, 1, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 16, 1, 2), RIB_V9(16, 4, 1, 1, 2, 16, 1, 1), RIB_V9(16, 4, 1, 1, 2, 16, 1, 2),
     RIB_V9(16, 4, 1, 1, 1, 32, 1, 2), RIB_V9(16, 4, 1, 1, 1, 32, 1, 4), RIB_V9(8, 2, 2, 1, 1, 16, 1, 2),
     RIB_V9(16, 4, 1, 2, 1, 16, 1, 2), RIB_V9(16, 4, 1, 2, 1, 32, 1, 2),
+    RIB_VU4(16, 4, 1, 1, 1, 32), RIB_VU4(16, 4, 1, 1, 1, 16), RIB_VU4(8, 2, 2, 1, 1, 32), RIB_VU4(8, 2, 2, 1, 1, 16),
     RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 2, 16, 2, 2), RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
