@@ -282,6 +282,11 @@ const Variant kVariants[] = {
     RIB_V9(16, 4, 1, 1, 1, 32, 1, 2), RIB_V9(16, 4, 1, 1, 1, 32, 1, 4), RIB_V9(8, 2, 2, 1, 1, 16, 1, 2),
     RIB_V9(16, 4, 1, 2, 1, 16, 1, 2), RIB_V9(16, 4, 1, 2, 1, 32, 1, 2),
     RIB_VU4(16, 4, 1, 1, 1, 32), RIB_VU4(16, 4, 1, 1, 1, 16), RIB_VU4(8, 2, 2, 1, 1, 32), RIB_VU4(8, 2, 2, 1, 1, 16),
+    // 16-column path with three / nine slices per barrier (the 16-channel layers on the 512x512 maps)
+    RIB_VT(16, 4, 1, 1, 0, 16, 1, false), RIB_VT(16, 4, 1, 2, 0, 16, 1, false), RIB_VT(16, 4, 1, 1, 0, 32, 1, false), RIB_VT(16, 4, 1, 2, 0, 32, 1, false),
+    RIB_V9(16, 4, 1, 1, 0, 16, 1, 1), RIB_V9(16, 4, 1, 2, 0, 16, 1, 1), RIB_V9(16, 4, 1, 1, 0, 32, 1, 1), RIB_V9(16, 4, 1, 2, 0, 32, 1, 1),
+    // 32-column single-fragment tiles with all nine slices per barrier, no wave groups (low-channel 512x512 layers)
+    RIB_V9(16, 4, 1, 1, 1, 32, 1, 1), RIB_V9(16, 4, 1, 2, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 8, 1, 1), RIB_V9(16, 4, 1, 1, 2, 8, 1, 1),
     RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 2, 16, 2, 2), RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
