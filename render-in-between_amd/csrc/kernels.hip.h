@@ -137,7 +137,8 @@ struct IgemmGeom {
   static constexpr int NB4 = (BN * BK / 4 + NT - 1) / NT; // float4 filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
-  static constexpr int SMEM0 = SA + 2 * TB * SB > SRED ? SA + 2 * TB * SB : SRED;
+  static constexpr int NA = TB == 9 ? 2 : 1;   // TB = 9 also double-buffers the input tile: one barrier per chunk
+  static constexpr int SMEM0 = NA * SA + 2 * TB * SB > SRED ? NA * SA + 2 * TB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
   static constexpr int TAPS = UPS ? 16 : KS * KS;   // filter slices per channel chunk (row stride of w)
 };
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   float* sA = smem;
-  float* sB = smem + G::SA;
+  float* sB = smem + G::NA * G::SA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -490,20 +491,25 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #endif
     }
   } else if constexpr (TB == 9) {
-    // all nine filter slices of a chunk staged at once (double-buffered across chunks): one barrier pair per chunk
+    // all nine filter slices of a chunk staged at once; input tile AND filters double-buffered across chunks, so a
+    // chunk costs ONE barrier: chunk k+1 is written to the other buffers right after the MFMAs of chunk k (its
+    // global loads were in flight during them); whoever is past the barrier of chunk k has finished chunk k-1
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
+    writeA(false);
+    storeB3(0);
     int stage = 0;
     for (int kc = kc_begin; kc < kc_end; kc += BK, ++stage) {
-      __syncthreads();
-      writeA(false);
       const int buf = stage & 1;
-      storeB3(buf);
-      if (kc + BK < kc_end) { loadB3(kc + BK, 0); prefetchA(kc + BK); }
+      const bool more = kc + BK < kc_end;
+      if (more) { loadB3(kc + BK, 0); prefetchA(kc + BK); }
       __syncthreads();
+      sA = smem + buf * G::SA;
 #pragma unroll
       for (int t = 0; t < 9; ++t) compute_tap(t / 3, t % 3, buf * 9 + t);
+      if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB3(buf ^ 1); }
     }
+    sA = smem;
   } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);

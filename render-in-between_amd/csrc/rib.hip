@@ -164,7 +164,7 @@ struct Variant {
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
-    const int main_loop = (ih * iwp * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;
+    const int main_loop = ((TB == 9 ? 2 : 1) * ih * iwp * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;   // IgemmGeom::NA
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
   }
@@ -280,14 +280,14 @@ const Variant kVariants[] = {
     RIB_VTK(8, 2, 2, 1, 1, 32, 2, 2),  RIB_VTK(16, 4, 1, 1, 2, 16, 2, 2),  RIB_VTK(8, 2, 2, 1, 1, 16, 2, 2),
     RIB_V9(16, 4, 1, 1, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 16, 1, 2), RIB_V9(16, 4, 1, 1, 2, 16, 1, 1), RIB_V9(16, 4, 1, 1, 2, 16, 1, 2),
     RIB_V9(16, 4, 1, 1, 1, 32, 1, 2), RIB_V9(16, 4, 1, 1, 1, 32, 1, 4), RIB_V9(8, 2, 2, 1, 1, 16, 1, 2),
-    RIB_V9(16, 4, 1, 2, 1, 16, 1, 2), RIB_V9(16, 4, 1, 2, 1, 32, 1, 2),
+    RIB_V9(16, 4, 1, 2, 1, 16, 1, 2),
     RIB_VU4(16, 4, 1, 1, 1, 32), RIB_VU4(16, 4, 1, 1, 1, 16), RIB_VU4(8, 2, 2, 1, 1, 32), RIB_VU4(8, 2, 2, 1, 1, 16),
     // 16-column path with three / nine slices per barrier (the 16-channel layers on the 512x512 maps)
     RIB_VT(16, 4, 1, 1, 0, 16, 1, false), RIB_VT(16, 4, 1, 2, 0, 16, 1, false), RIB_VT(16, 4, 1, 1, 0, 32, 1, false), RIB_VT(16, 4, 1, 2, 0, 32, 1, false),
     RIB_V9(16, 4, 1, 1, 0, 16, 1, 1), RIB_V9(16, 4, 1, 2, 0, 16, 1, 1), RIB_V9(16, 4, 1, 1, 0, 32, 1, 1), RIB_V9(16, 4, 1, 2, 0, 32, 1, 1),
     // 32-column single-fragment tiles with all nine slices per barrier, no wave groups (low-channel 512x512 layers)
     RIB_V9(16, 4, 1, 1, 1, 32, 1, 1), RIB_V9(16, 4, 1, 2, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 8, 1, 1), RIB_V9(16, 4, 1, 1, 2, 8, 1, 1),
-    RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 2, 16, 2, 2), RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
+    RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
     // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
     // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
     RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
