@@ -153,3 +153,26 @@ def test_generator_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         rib.Generator(rib.hsm_gen_config())
+
+
+def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
+    """tuning.apply() silently falls back to the cost model for a geometry that is no longer in the variant
+    table: after editing the table, stale entries would go unnoticed.  Every entry must resolve."""
+    import json
+    from render_in_between_amd import tuning
+    g12 = (C.c_int * 12)()
+    geoms = set()
+    for i in range(lib.rib_num_variants()):
+        if lib.rib_variant_info(i, g12) == 0:            # fp32 variants (the table is measured in fp32)
+            geoms.add(tuple(g12))
+    table = tuning.load()
+    assert "1,512,512" in table and len(table["1,512,512"]) >= 60
+    stale = []
+    for shape, entry in table.items():
+        for op, ch in entry.items():
+            kw = int(ch[11]) if len(ch) > 11 else 1
+            tb = int(ch[12]) if len(ch) > 12 else 1
+            if tuple(ch[:10]) + (kw, tb) not in geoms:
+                stale.append((shape, op, ch))
+            assert int(ch[10]) >= 1
+    assert not stale, stale[:5]
