@@ -113,6 +113,10 @@ int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const fl
  *   prev <- fuse_t.
  * labels [T,B,label_nc,H,W], dains [T,B,image_nc,H,W], key_frame [B,image_nc,H,W];
  * outputs imgs/fuses [T,B,image_nc,H,W], masks [T,B,1,H,W]; imgs and masks may be NULL. */
+/* Workspace for a T-frame rib_chain: rib_workspace_bytes plus room for the label-only launches of the whole
+ * segment at batch T*B (they run once per chain instead of once per frame).  A caller that passes only
+ * rib_workspace_bytes still gets a correct chain with per-frame label work. */
+size_t rib_chain_workspace_bytes(rib_handle* h, int T, int B, int H, int W);
 int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
               const float* labels, const float* dains, float* imgs, float* masks, float* fuses,
               void* workspace, size_t workspace_bytes, void* hip_stream);

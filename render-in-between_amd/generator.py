@@ -219,6 +219,16 @@ class Generator:
         key_frame = self._prep(key_frame, s.image_nc, "key_frame", (B, H, W))
         assert labels.shape == (T, B, s.label_nc, H, W) and dains.shape == (T, B, s.image_nc, H, W)
         ws = self._workspace(B, H, W)
+        need = int(self._lib.rib_chain_workspace_bytes(self._h, T, B, H, W))      # + the batched label-only launches
+        if need > ws.numel():
+            cws = self._chain_ws.get((T, B, H, W)) if hasattr(self, "_chain_ws") else None
+            if cws is None:
+                if not hasattr(self, "_chain_ws"):
+                    self._chain_ws = {}
+                self._chain_ws.clear()                                             # one chain shape at a time
+                cws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._chain_ws[(T, B, H, W)] = cws
+            ws = cws
         fuses = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
         imgs = torch.empty_like(fuses) if want_all else None
         masks = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=self.device) if want_all else None

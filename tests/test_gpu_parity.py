@@ -448,3 +448,30 @@ def test_upsample_convolutions_as_phase_convolutions_match_oracle_at_odd_sizes()
         img, mask = G(label, None, fake, prev)
         ri, rm = R(label, None, fake, prev)
         assert float((img.cpu() - ri).abs().max()) < TOL and float((mask.cpu() - rm).abs().max()) < TOL, (B, H, W)
+
+
+def test_chain_with_batched_label_work_matches_the_per_frame_chain(monkeypatch):
+    """rib_chain runs the label-only launches (pack.label, down_first, the mask network's label branch) once for
+    the whole segment at batch T*B; with RIB_NO_LABEL_BATCH they run per frame.  Same frames either way, bit for
+    bit (the batched launches use the frame plan's kernel choices), and they match the oracle loop."""
+    spec, sd, G = build("full", 0)
+    T, H, W = 5, 64, 96
+    labels = torch.stack([synth.make_inputs(spec, 1, H, W, 40 + t)[0] for t in range(T)])
+    dains = torch.stack([synth.make_inputs(spec, 1, H, W, 40 + t)[1] for t in range(T)])
+    key = synth.make_inputs(spec, 1, H, W, 39)[2]
+    monkeypatch.delenv("RIB_NO_LABEL_BATCH", raising=False)
+    i1, m1, f1 = [t.clone() for t in G.chain(key, labels, dains)]
+    assert G._lib.rib_chain_workspace_bytes(G._h, T, 1, H, W) > G._lib.rib_workspace_bytes(G._h, 1, H, W)
+    monkeypatch.setenv("RIB_NO_LABEL_BATCH", "1")
+    assert G._lib.rib_chain_workspace_bytes(G._h, T, 1, H, W) == G._lib.rib_workspace_bytes(G._h, 1, H, W)
+    i2, m2, f2 = G.chain(key, labels, dains)
+    torch.cuda.synchronize()
+    # the batched launches follow the frame plan's kernel choices: bit-identical frames
+    assert torch.equal(f1, f2) and torch.equal(m1, m2) and torch.equal(i1, i2)
+    R = oracle(spec, sd)
+    from oracle import generator_ref
+    prev = key
+    for t in range(T):
+        oi, om = R(labels[t], None, dains[t], prev)
+        prev = generator_ref.blend(oi, om, dains[t])
+        assert float((f1[t].cpu() - prev).abs().max()) < TOL, t
