@@ -1277,6 +1277,20 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_gather6: up to six device-to-device copies in one launch (rib_chain: a frame's slices of the batched
+// label-only results into the frame plan's slots).  Sizes are multiples of 16 bytes; grid (blocks, 6).
+// ---------------------------------------------------------------------------------------------
+struct Gather6Params { const float4* src[6]; float4* dst[6]; unsigned n4[6]; };
+
+__global__ __launch_bounds__(256) void k_gather6(const Gather6Params p) {
+  const int r = blockIdx.y;
+  const float4* s = p.src[r];
+  float4* d = p.dst[r];
+  const unsigned n = p.n4[r];
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_pack: concatenate up to 3 NCHW sources along channels into one zero-padded NHWC tensor
 // (torch.cat at PGNR/models/generator.py:197,232 and the NCHW->NHWC boundary conversion).
 // 64 pixels per 256-thread block; grid (ceil(HW/64), B); dC <= 32.

@@ -1664,8 +1664,13 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
       const LabelSlots& a = PL->ls; const LabelSlots& b = P->ls;   // a: [T*B] batch, b: [B] batch
       struct { size_t src, dst, bytes; } cp[6] = {{a.x0, b.x0, b.x0_b}, {a.nx_sc, b.nx_sc, b.nx_b}, {a.nx_sh, b.nx_sh, b.nx_b},
                                                    {a.cat, b.cat, b.cat_b}, {a.ncat_sc, b.ncat_sc, b.ncat_b}, {a.ncat_sh, b.ncat_sh, b.ncat_b}};
-      for (auto& c6 : cp)
-        HIP_TRY(h, hipMemcpyAsync(wsb + c6.dst, lws + c6.src + (size_t)t * c6.bytes, c6.bytes, hipMemcpyDeviceToDevice, st));
+      Gather6Params gp;
+      for (int k = 0; k < 6; ++k) {
+        gp.src[k] = reinterpret_cast<const float4*>(lws + cp[k].src + (size_t)t * cp[k].bytes);
+        gp.dst[k] = reinterpret_cast<float4*>(wsb + cp[k].dst);
+        gp.n4[k] = (unsigned)(cp[k].bytes / 16);       // every slot is a whole number of 8-channel (32-byte) groups
+      }
+      hipLaunchKernelGGL(k_gather6, dim3(1024, 6), dim3(256), 0, st, gp);
     }
     float* img_t = imgs ? imgs + (size_t)t * frame : tmp_img;
     float* mask_t = masks ? masks + (size_t)t * mframe : tmp_mask;
