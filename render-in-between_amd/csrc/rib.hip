@@ -1800,6 +1800,12 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
     h->choices[key] = {variant_idx, ksplit};
   }
   h->plans.erase(((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W);   // rebuilt on next use
+  // ... and the labels-only plans of chains that follow this shape's choices (key: labels bit, tuneB, T*B, H, W)
+  for (auto it = h->plans.begin(); it != h->plans.end();) {
+    const uint64_t k = it->first;
+    const bool follows = (k >> 63) && (int)((k >> 56) & 0x7f) == B && (int)((k >> 20) & 0xfffff) == H && (int)(k & 0xfffff) == W;
+    if (follows) it = h->plans.erase(it); else ++it;
+  }
   return RIB_OK;
 }
 
