@@ -1612,7 +1612,10 @@ int rib_rasterise(rib_handle* h, int T, int H, int W, const rib_stroke* strokes,
 
 namespace {
 // label-only work is batched over the chain when it has more than one frame, on one stream (RIB_NO_LABEL_BATCH=1 disables)
-bool chain_batches_labels(const rib_handle* h, int T, int B) { return T > 1 && B < 128 && !h->use_streams && !getenv("RIB_NO_LABEL_BATCH"); }
+bool chain_batches_labels(const rib_handle* h, int T, int B) {
+  // T * B * split-K (<= 16) indexes blockIdx.z (< 65536) of the batched launches
+  return T > 1 && B < 128 && (long)T * B < 4096 && !h->use_streams && !getenv("RIB_NO_LABEL_BATCH");
+}
 }  // namespace
 
 size_t rib_chain_workspace_bytes(rib_handle* h, int T, int B, int H, int W) {
