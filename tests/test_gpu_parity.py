@@ -475,3 +475,29 @@ def test_chain_with_batched_label_work_matches_the_per_frame_chain(monkeypatch):
         oi, om = R(labels[t], None, dains[t], prev)
         prev = generator_ref.blend(oi, om, dains[t])
         assert float((f1[t].cpu() - prev).abs().max()) < TOL, t
+
+
+def test_full_size_properties_512():
+    """Size-independent properties at BASELINE.json's full size (512x512), where the oracle is only run once:
+    batch independence (a sample's frame does not depend on its batch mates), determinism, label_prev is dead,
+    the mask is a probability, the blend is the convex combination of evaluator.py:256-258, quantise is idempotent
+    on already quantised values, and the uint8 frame is what the oracle's quantiser makes of the same floats."""
+    from oracle import generator_ref
+    spec, sd, G = build("full", 0)
+    label, fake, prev = synth.make_inputs(spec, 2, 512, 512, 11)
+    i2, m2 = [t.clone() for t in G(label, None, fake, prev)]
+    j2, n2 = G(label, torch.zeros_like(label), fake, prev)
+    assert torch.equal(i2, j2) and torch.equal(m2, n2)
+    for b in range(2):
+        i1, m1 = G(label[b:b + 1], None, fake[b:b + 1], prev[b:b + 1])
+        assert float((i1 - i2[b:b + 1]).abs().max()) <= 5e-5 and float((m1 - m2[b:b + 1]).abs().max()) <= 5e-5
+    assert float(i2.abs().max()) <= 1.0 and 0.0 <= float(m2.min()) and float(m2.max()) <= 1.0
+    fuse = G.blend(i2, m2, fake)
+    lo = torch.minimum(i2, fake.to(i2.device)) - 1e-6
+    hi = torch.maximum(i2, fake.to(i2.device)) + 1e-6
+    assert bool(((fuse >= lo) & (fuse <= hi)).all())                     # convex combination, channel by channel
+    q = G.quantise(fuse)
+    assert np.array_equal(q.cpu().numpy(), np.stack([generator_ref.quantise_uint8(fuse[b:b + 1].cpu()) for b in range(2)]).reshape(q.shape))
+    back = (q.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+    q2 = G.quantise(back + 1e-4)      # already on the uint8 grid (nudged off the truncation edge): unchanged
+    assert torch.equal(q, q2)
