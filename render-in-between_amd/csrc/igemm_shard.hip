@@ -1,0 +1,66 @@
+// igemm_shard.hip - one section of the k_igemm tile variants (variants.def), compiled once per section
+// with -DRIB_SECTION=<0..7> so that the kernel code generation runs as parallel hipcc jobs.
+// Taking a kernel's address instantiates it in this object; rib.hip refers to it through `extern template`.
+#define RIB_IGEMM_ONLY 1
+#include "kernels.hip.h"
+#include "variants.hip.h"
+
+#ifndef RIB_SECTION
+#error "compile with -DRIB_SECTION=<n>"
+#endif
+
+#define RIB_CAT_(a, b) a##b
+#define RIB_CAT(a, b) RIB_CAT_(a, b)
+#define RIB_KEEP(...) __VA_ARGS__
+#define RIB_DROP(...)
+// RIB_ON_<s> keeps its arguments only for this object's section
+#define RIB_ON_0 RIB_DROP
+#define RIB_ON_1 RIB_DROP
+#define RIB_ON_2 RIB_DROP
+#define RIB_ON_3 RIB_DROP
+#define RIB_ON_4 RIB_DROP
+#define RIB_ON_5 RIB_DROP
+#define RIB_ON_6 RIB_DROP
+#define RIB_ON_7 RIB_DROP
+#if RIB_SECTION == 0
+#undef RIB_ON_0
+#define RIB_ON_0 RIB_KEEP
+#elif RIB_SECTION == 1
+#undef RIB_ON_1
+#define RIB_ON_1 RIB_KEEP
+#elif RIB_SECTION == 2
+#undef RIB_ON_2
+#define RIB_ON_2 RIB_KEEP
+#elif RIB_SECTION == 3
+#undef RIB_ON_3
+#define RIB_ON_3 RIB_KEEP
+#elif RIB_SECTION == 4
+#undef RIB_ON_4
+#define RIB_ON_4 RIB_KEEP
+#elif RIB_SECTION == 5
+#undef RIB_ON_5
+#define RIB_ON_5 RIB_KEEP
+#elif RIB_SECTION == 6
+#undef RIB_ON_6
+#define RIB_ON_6 RIB_KEEP
+#elif RIB_SECTION == 7
+#undef RIB_ON_7
+#define RIB_ON_7 RIB_KEEP
+#else
+#error "RIB_SECTION out of range"
+#endif
+
+#define RIB_V(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_V(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VK(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VK(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VT(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VT(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VTK(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VTK(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_V9(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_V9(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VU4(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VU4(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VS(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VS(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VSK(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VSK(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VB(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VB(RIB_F_TOUCH, __VA_ARGS__))
+
+typedef void (*IgemmFn)(const rib::IgemmParams);
+extern "C" __attribute__((used, visibility("hidden"))) IgemmFn const RIB_CAT(rib_igemm_section_, RIB_SECTION)[] = {
+#include "variants.def"
+    nullptr};

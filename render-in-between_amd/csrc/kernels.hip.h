@@ -847,6 +847,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   }
 }
 
+#ifndef RIB_IGEMM_ONLY   // igemm_shard.hip compiles k_igemm only; everything below is instantiated by rib.hip
 // ---------------------------------------------------------------------------------------------
 // k_stats_finalize: per-tile partial sums -> (scale, shift) of the InstanceNorm that follows.
 //   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
@@ -1392,5 +1393,7 @@ __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flo
     out[((size_t)n * C + c) * HW + pix] = v;
   }
 }
+
+#endif  // RIB_IGEMM_ONLY
 
 }  // namespace rib

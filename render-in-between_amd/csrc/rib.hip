@@ -24,6 +24,29 @@
 #include <string>
 #include <vector>
 
+
+// ---- the k_igemm instantiations live in the igemm_shard_<s>.o objects (variants.def, build.py) ----
+#include "variants.hip.h"
+#define RIB_V(sec, ...) RIB_I_V(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VK(sec, ...) RIB_I_VK(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VT(sec, ...) RIB_I_VT(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VTK(sec, ...) RIB_I_VTK(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_V9(sec, ...) RIB_I_V9(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VU4(sec, ...) RIB_I_VU4(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VS(sec, ...) RIB_I_VS(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VSK(sec, ...) RIB_I_VSK(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VB(sec, ...) RIB_I_VB(RIB_F_EXTERN, __VA_ARGS__)
+#include "variants.def"
+#undef RIB_V
+#undef RIB_VK
+#undef RIB_VT
+#undef RIB_VTK
+#undef RIB_V9
+#undef RIB_VU4
+#undef RIB_VS
+#undef RIB_VSK
+#undef RIB_VB
+
 using namespace rib;
 
 namespace {
@@ -172,49 +195,49 @@ struct Variant {
 // RIB_V: convolution geometries, three instantiations (generic / no shortcut loop / lean); the
 // shortcut loop only exists for 3x3 stride-1 gathers, elsewhere "generic" already is "pro".
 // RIB_VS: SPADE geometries (one instantiation).  RIB_VB: bf16 twins (generic only).
-#define RIB_V(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP)                                                         \
+#define RIB_V(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP)                                                         \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                             \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, (KS == 3 && S == 1 && !UPS), true>, false,   \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, true>,                               \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, false>}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, false>},
 // RIB_VK: in-workgroup split-K twin of a convolution geometry (fp32, 32-column path)
-#define RIB_VK(FRW, WM, WN, MF, NF, BK, S, KS, UPS, KW)                                                                  \
+#define RIB_VK(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, KW)                                                                  \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, false,                                                                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, (KS == 3 && S == 1 && !UPS), true, KW>, false,      \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, true, KW>,                                  \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, false, KW>, KW}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, false, KW>, KW},
 // RIB_VT: three-taps-per-barrier twin of a 3x3 convolution geometry
-#define RIB_VT(FRW, WM, WN, MF, NF, BK, S, UPS)                                                                         \
+#define RIB_VT(sec, FRW, WM, WN, MF, NF, BK, S, UPS)                                                                         \
   Variant{FRW, WM, WN, MF, NF, BK, S, 3, UPS, false,                                                                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, (S == 1 && !UPS), true, 1, 3>, false,               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, true, 1, 3>,                                \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3>, 1, 3}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3>, 1, 3},
 // RIB_VTK: three taps per barrier AND KW wave groups per tile (8 / 16 waves share the 3-slice filter buffers)
-#define RIB_VTK(FRW, WM, WN, MF, NF, BK, S, KW)                                                                         \
+#define RIB_VTK(sec, FRW, WM, WN, MF, NF, BK, S, KW)                                                                         \
   Variant{FRW, WM, WN, MF, NF, BK, S, 3, false, false,                                                                  \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 3>, false,                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 3>,                             \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 3>, KW, 3}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 3>, KW, 3},
 // RIB_V9: all nine filter slices of a chunk per barrier pair (TB = 9), optionally with KW wave groups
-#define RIB_V9(FRW, WM, WN, MF, NF, BK, S, KW)                                                                          \
+#define RIB_V9(sec, FRW, WM, WN, MF, NF, BK, S, KW)                                                                          \
   Variant{FRW, WM, WN, MF, NF, BK, S, 3, false, false,                                                                  \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 9>, false,                    \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 9>,                             \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 9>, KW, 9}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 9>, KW, 9},
 // RIB_VU4: phase-decomposed upsample convolution with the four taps of a phase per barrier (TB = 4)
-#define RIB_VU4(FRW, WM, WN, MF, NF, BK)                                                                                \
+#define RIB_VU4(sec, FRW, WM, WN, MF, NF, BK)                                                                                \
   Variant{FRW, WM, WN, MF, NF, BK, 1, 3, true, false,                                                                   \
           &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4>, false,                         \
           &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4>,                               \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, false, 1, 4>, 1, 4}
-#define RIB_VS(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
-  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false}
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, false, 1, 4>, 1, 4},
+#define RIB_VS(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false>, false},
 // RIB_VSK: in-workgroup split-K twin of a SPADE geometry: the fused kernel on the small deep maps with 8 / 16 waves
 // per tile instead of the unfused pair (split-K GEMM into slabs + k_spade_modulate)
-#define RIB_VSK(FRW, WM, WN, MF, NF, BK, KW) \
-  Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW}
-#define RIB_VB(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
-  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true}
+#define RIB_VSK(sec, FRW, WM, WN, MF, NF, BK, KW) \
+  Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW},
+#define RIB_VB(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true},
 
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
@@ -224,82 +247,7 @@ inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
 }
 
 const Variant kVariants[] = {
-    // 3x3 stride 1, tile 8x16 (4 waves along M), BN 32 / 64
-    RIB_V(16, 4, 1, 1, 1, 8, 1, 3, false, false),  RIB_V(16, 4, 1, 1, 2, 8, 1, 3, false, false),
-    RIB_V(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 3, false, false),
-    RIB_V(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 3, false, false),
-    // 3x3 stride 1, small tiles for the deep, small-spatial layers
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 1, 32, 1, 3, false, false),
-    RIB_V(8, 2, 2, 1, 1, 16, 1, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 1, 3, false, false),
-    // 3x3 stride 1, 16x16 tile (two fragments per wave)
-    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 16, 1, 3, false, false),
-    RIB_V(16, 4, 1, 2, 1, 32, 1, 3, false, false), RIB_V(16, 4, 1, 2, 2, 32, 1, 3, false, false),
-    RIB_V(16, 4, 1, 1, 4, 16, 1, 3, false, false),
-    // 3x3 stride 1, 16-column path (v_mfma_f32_16x16x4_f32) for <= 16 output channels
-    RIB_V(16, 4, 1, 1, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 1, 0, 32, 1, 3, false, false),
-    RIB_V(16, 4, 1, 2, 0, 16, 1, 3, false, false), RIB_V(16, 4, 1, 2, 0, 32, 1, 3, false, false),
-    // 3x3 stride 2
-    RIB_V(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_V(8, 1, 4, 1, 1, 32, 2, 3, false, false),
-    RIB_V(8, 2, 2, 1, 1, 16, 2, 3, false, false),  RIB_V(8, 2, 2, 1, 2, 16, 2, 3, false, false),
-    RIB_V(16, 4, 1, 1, 1, 16, 2, 3, false, false), RIB_V(16, 4, 1, 1, 2, 16, 2, 3, false, false),
-    RIB_V(8, 2, 2, 2, 1, 16, 2, 3, false, false),
-    // 3x3 on a nearest-x2-upsampled input, phase-decomposed: the tile is in SOURCE pixels, four
-    // accumulator sets per wave (MF * NF <= 2 keeps them within 128 registers)
-    RIB_V(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 32, 1, 3, true, false),
-    RIB_V(16, 4, 1, 1, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 1, 2, 16, 1, 3, true, false),
-    RIB_V(16, 4, 1, 2, 1, 16, 1, 3, true, false),  RIB_V(16, 4, 1, 2, 1, 32, 1, 3, true, false),
-    RIB_V(8, 2, 2, 1, 1, 32, 1, 3, true, false),   RIB_V(8, 2, 2, 1, 1, 16, 1, 3, true, false),
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 3, true, false),
-    // 1x1
-    RIB_V(16, 4, 1, 1, 1, 16, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 16, 1, 1, false, false),
-    RIB_V(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_V(16, 4, 1, 1, 2, 32, 1, 1, false, false),
-    RIB_V(8, 1, 4, 1, 1, 32, 1, 1, false, false),  RIB_V(16, 4, 1, 1, 2, 64, 1, 1, false, false),
-    RIB_V(8, 2, 2, 1, 1, 64, 1, 1, false, false),
-    // SPADE: 1x1 gamma/beta GEMM on the condition map + modulate epilogue
-    RIB_VS(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_VS(8, 1, 4, 1, 2, 32, 1, 1, false, true),
-    RIB_VS(16, 4, 1, 1, 2, 64, 1, 1, false, true),  RIB_VS(8, 2, 2, 1, 2, 64, 1, 1, false, true),
-    RIB_VS(16, 4, 1, 1, 4, 32, 1, 1, false, true),  RIB_VS(16, 4, 1, 2, 2, 32, 1, 1, false, true),
-    RIB_VS(16, 4, 1, 2, 2, 64, 1, 1, false, true),
-    // ---- in-workgroup split-K twins (8 or 16 waves per tile) for the launches that cannot fill the chip ----
-    RIB_VK(16, 4, 1, 1, 1, 32, 1, 3, false, 2), RIB_VK(16, 4, 1, 1, 1, 32, 1, 3, false, 4),
-    RIB_VK(16, 4, 1, 1, 2, 32, 1, 3, false, 2), RIB_VK(16, 4, 1, 2, 1, 32, 1, 3, false, 2),
-    RIB_VK(8, 2, 2, 1, 1, 32, 1, 3, false, 2),  RIB_VK(8, 2, 2, 1, 1, 32, 1, 3, false, 4),
-    RIB_VK(16, 4, 1, 1, 1, 16, 1, 3, false, 2),
-    RIB_VK(8, 2, 2, 1, 1, 32, 2, 3, false, 2),  RIB_VK(8, 2, 2, 1, 1, 32, 2, 3, false, 4),
-    RIB_VK(8, 2, 2, 1, 1, 16, 2, 3, false, 2),  RIB_VK(16, 4, 1, 1, 1, 16, 2, 3, false, 2),
-    RIB_VK(16, 4, 1, 1, 1, 32, 1, 1, false, 2), RIB_VK(16, 4, 1, 1, 2, 32, 1, 1, false, 2),
-    RIB_VK(16, 4, 1, 1, 2, 64, 1, 1, false, 2), RIB_VK(8, 2, 2, 1, 1, 64, 1, 1, false, 2),
-    RIB_VSK(16, 4, 1, 1, 2, 64, 2), RIB_VSK(16, 4, 1, 1, 2, 64, 4), RIB_VSK(8, 2, 2, 1, 2, 64, 2), RIB_VSK(8, 2, 2, 1, 2, 64, 4),
-    RIB_VSK(16, 4, 1, 1, 2, 32, 2), RIB_VSK(16, 4, 1, 1, 2, 32, 4),
-    // ---- three-taps-per-barrier twins for launches with LDS to spare (<= 2 workgroups per CU) ----
-    RIB_VT(16, 4, 1, 1, 1, 32, 1, false), RIB_VT(16, 4, 1, 1, 2, 32, 1, false), RIB_VT(16, 4, 1, 2, 1, 32, 1, false),
-    RIB_VT(8, 2, 2, 1, 1, 32, 1, false),  RIB_VT(16, 4, 1, 1, 1, 16, 1, false), RIB_VT(16, 4, 1, 1, 2, 16, 1, false),
-    RIB_VT(8, 2, 2, 1, 1, 32, 2, false),  RIB_VT(8, 2, 2, 1, 1, 16, 2, false),  RIB_VT(16, 4, 1, 1, 2, 16, 2, false),
-    RIB_VTK(16, 4, 1, 1, 1, 32, 1, 2), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 2), RIB_VTK(16, 4, 1, 2, 1, 32, 1, 2), RIB_VTK(8, 2, 2, 1, 1, 32, 1, 2),
-    RIB_VTK(16, 4, 1, 1, 1, 32, 1, 4), RIB_VTK(16, 4, 1, 1, 2, 32, 1, 4),
-    RIB_VTK(8, 2, 2, 1, 1, 32, 2, 2),  RIB_VTK(16, 4, 1, 1, 2, 16, 2, 2),  RIB_VTK(8, 2, 2, 1, 1, 16, 2, 2),
-    RIB_V9(16, 4, 1, 1, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 16, 1, 2), RIB_V9(16, 4, 1, 1, 2, 16, 1, 1), RIB_V9(16, 4, 1, 1, 2, 16, 1, 2),
-    RIB_V9(16, 4, 1, 1, 1, 32, 1, 2), RIB_V9(16, 4, 1, 1, 1, 32, 1, 4), RIB_V9(8, 2, 2, 1, 1, 16, 1, 2),
-    RIB_V9(16, 4, 1, 2, 1, 16, 1, 2),
-    RIB_VU4(16, 4, 1, 1, 1, 32), RIB_VU4(16, 4, 1, 1, 1, 16), RIB_VU4(8, 2, 2, 1, 1, 32), RIB_VU4(8, 2, 2, 1, 1, 16),
-    // 16-column path with three / nine slices per barrier (the 16-channel layers on the 512x512 maps)
-    RIB_VT(16, 4, 1, 1, 0, 16, 1, false), RIB_VT(16, 4, 1, 2, 0, 16, 1, false), RIB_VT(16, 4, 1, 1, 0, 32, 1, false), RIB_VT(16, 4, 1, 2, 0, 32, 1, false),
-    RIB_V9(16, 4, 1, 1, 0, 16, 1, 1), RIB_V9(16, 4, 1, 2, 0, 16, 1, 1), RIB_V9(16, 4, 1, 1, 0, 32, 1, 1), RIB_V9(16, 4, 1, 2, 0, 32, 1, 1),
-    // 32-column single-fragment tiles with all nine slices per barrier, no wave groups (low-channel 512x512 layers)
-    RIB_V9(16, 4, 1, 1, 1, 32, 1, 1), RIB_V9(16, 4, 1, 2, 1, 16, 1, 1), RIB_V9(16, 4, 1, 1, 1, 8, 1, 1), RIB_V9(16, 4, 1, 1, 2, 8, 1, 1),
-    RIB_V9(8, 2, 2, 1, 1, 16, 2, 1),  RIB_V9(8, 2, 2, 1, 1, 16, 2, 2),  RIB_V9(16, 4, 1, 1, 1, 16, 2, 2),
-    // ---- bf16 matrix-core twins (rib_set_compute_dtype(RIB_DTYPE_BF16)); layers without a twin
-    // (8-channel chunks, the 16-column path) keep the fp32 kernels ----
-    RIB_VB(16, 4, 1, 1, 1, 16, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 16, 1, 3, false, false),
-    RIB_VB(16, 4, 1, 1, 1, 32, 1, 3, false, false), RIB_VB(16, 4, 1, 1, 2, 32, 1, 3, false, false),
-    RIB_VB(8, 2, 2, 1, 1, 32, 1, 3, false, false),  RIB_VB(8, 2, 2, 1, 1, 16, 1, 3, false, false),
-    RIB_VB(8, 2, 2, 1, 1, 32, 2, 3, false, false),  RIB_VB(8, 2, 2, 1, 1, 16, 2, 3, false, false),
-    RIB_VB(8, 2, 2, 1, 2, 16, 2, 3, false, false),
-    RIB_VB(16, 4, 1, 1, 1, 32, 1, 3, true, false),  RIB_VB(16, 4, 1, 1, 2, 32, 1, 3, true, false),
-    RIB_VB(16, 4, 1, 1, 1, 32, 1, 1, false, false), RIB_VB(16, 4, 1, 1, 2, 32, 1, 1, false, false),
-    RIB_VB(16, 4, 1, 1, 2, 64, 1, 1, false, false), RIB_VB(8, 2, 2, 1, 1, 64, 1, 1, false, false),
-    RIB_VB(16, 4, 1, 1, 2, 32, 1, 1, false, true),  RIB_VB(16, 4, 1, 1, 2, 64, 1, 1, false, true),
-    RIB_VB(8, 2, 2, 1, 2, 64, 1, 1, false, true),
+#include "variants.def"
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

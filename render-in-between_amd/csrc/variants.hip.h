@@ -1,0 +1,44 @@
+// variants.hip.h - which k_igemm instantiations a table entry of variants.def stands for.
+//
+// RIB_I_<kind>(F, args...) applies F to the template-argument list of every instantiation of an entry:
+//   RIB_F_EXTERN  -> `extern template` declaration (rib.hip: the code lives in a shard object)
+//   RIB_F_TOUCH   -> `&k_igemm<...>,` (igemm_shard.hip: taking the address instantiates the kernel there)
+// rib.hip's RIB_V / RIB_VK / ... table macros name the same instantiations; keep the two in step.
+#pragma once
+
+// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, BF16, AUX, PRO, KW, TB
+#define RIB_F_EXTERN(...) extern template __global__ void rib::k_igemm<__VA_ARGS__>(const rib::IgemmParams);
+#define RIB_F_TOUCH(...) &rib::k_igemm<__VA_ARGS__>,
+
+// convolution geometry: generic (fused-shortcut loop + prologue) / no shortcut loop / lean
+#define RIB_I_V(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP)                                   \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, (KS == 3 && S == 1 && !UPS), true)        \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, true)                              \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false, false, false)
+// in-workgroup split-K twin (KW wave groups)
+#define RIB_I_VK(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, KW)                                       \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, (KS == 3 && S == 1 && !UPS), true, KW)      \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, true, KW)                            \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, false, false, false, false, KW)
+// three filter slices per barrier
+#define RIB_I_VT(F, FRW, WM, WN, MF, NF, BK, S, UPS)                                      \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, (S == 1 && !UPS), true, 1, 3)       \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, true, 1, 3)                  \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, UPS, false, false, false, false, 1, 3)
+#define RIB_I_VTK(F, FRW, WM, WN, MF, NF, BK, S, KW)                                      \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 3)            \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 3)               \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 3)
+// all nine filter slices per barrier pair
+#define RIB_I_V9(F, FRW, WM, WN, MF, NF, BK, S, KW)                                       \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, (S == 1), true, KW, 9)            \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, true, KW, 9)               \
+  F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, false, false, false, KW, 9)
+// phase-decomposed upsample convolution, four taps of a phase per barrier
+#define RIB_I_VU4(F, FRW, WM, WN, MF, NF, BK)                                             \
+  F(FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4)                 \
+  F(FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, false, 1, 4)
+// SPADE geometry / its in-workgroup split-K twin / bf16 matrix-core twin
+#define RIB_I_VS(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false)
+#define RIB_I_VSK(F, FRW, WM, WN, MF, NF, BK, KW) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW)
+#define RIB_I_VB(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true)
