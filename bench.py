@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — rendered frames/s of the generator forward (+ blend) at 512x512.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode frame|chain|clips]
 
-A "step" is one pass of the hot path over one batch of synthetic input: one
-512x512 frame (B=1, fp32) through Generator.forward plus the driver's blend,
-device-resident (BASELINE.json configs[1]).  For N>1 the driver launches one
-rank per GPU (torch.distributed.run); rank 0 builds the weights, they reach the
-other ranks through ONE RCCL broadcast of the folded blob, and every rank then
-renders its own frames with no further communication (weak scaling).
+A "step" is one pass of the hot path over one batch of synthetic input:
+  frame  (default) one 512x512 frame (B=1, fp32) through Generator.forward plus the driver's blend,
+         device-resident (BASELINE.json configs[1]);
+  chain  one autoregressive segment of --frames dependent frames (configs[2] shape);
+  clips  every rank renders its OWN --frames-frame clip (seeds 1000*rank + t) per step: BASELINE.json
+         configs[3], "8 independent 32-frame clips sharded over 8 GPUs, RCCL weight bcast".
+
+`--gpus N` with N > 1: when this process is not a rank yet (WORLD_SIZE unset) it starts the N ranks itself as child
+processes (python -m torch.distributed.run, one per GPU) BEFORE touching the GPU, relays rank 0's JSON line and exits
+with their code; the driver's own torch.distributed.run launch takes the other branch.  Rank 0 builds the weights,
+they reach the other ranks through ONE RCCL broadcast of the folded blob, and every rank then renders its own
+frames with no further communication (weak scaling).
 
 Printed JSON (rank 0): metric/value/unit as the contract asks, plus
-  roofline     dominant kernel class (the MFMA implicit-GEMM convolutions):
-               algorithmic FLOPs per forward / device time of those launches,
-               measured with HIP events on the launch stream in a separate
-               profiling pass, against the dense fp32 MFMA peak
-  cpu_baseline the CPU oracle (PyTorch fp32 restatement of the reference)
-               timed on this box's host cores on the same workload.
+  roofline     dominant kernel class (the MFMA implicit-GEMM convolutions): algorithmic FLOPs per forward / device
+               time of those launches, measured with HIP events on the launch stream in a separate profiling
+               pass, against the dense fp32 MFMA peak
+  cpu_baseline the CPU oracle (PyTorch fp32 restatement of the reference) timed on this box's host cores on the
+               same workload (rank 0 at N=1 only).
 """
 import argparse
 import json
@@ -27,51 +32,84 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch                                    # noqa: E402
+import torch                                    # noqa: E402  (importing torch does not initialise the GPU)
 
 PEAK_F32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_BF16_MFMA_TFLOPS = 2500.0                  # dense bf16 matrix
 PEAK_HBM_GBS = 8000.0
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--mode", choices=("frame", "chain"), default="frame",
-                    help="frame: one forward+blend per step (BASELINE configs[1], the default); "
-                         "chain: one autoregressive segment of --frames dependent frames per step (configs[2]/[3] shape)")
+    ap.add_argument("--mode", choices=("frame", "chain", "clips"), default="frame",
+                    help="frame: one forward+blend per step (BASELINE configs[1], the default); chain: one autoregressive "
+                         "segment of --frames dependent frames per step (configs[2] shape); clips: each rank renders its own "
+                         "--frames-frame clip per step and the replicas are checked against a 1-GPU run (configs[3])")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 (default, the reference's arithmetic) or bf16 matrix-core operands with fp32 "
-                         "accumulate/statistics/storage (BASELINE configs[2])")
+                    help="f32 (default, the reference's arithmetic) or bf16 (BASELINE configs[2]; a separately reported mode)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frames in flight per GPU: each on its own HIP stream with its own handle and "
                          "workspace (segments between key frames are independent, SURVEY F9); every forward stays batch=B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-frames", type=int, default=8, help="timed CPU-oracle passes of the cpu_baseline leg (>= 5)")
+    return ap.parse_args(argv)
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def clip_inputs(spec, synth, r, T, H, W):
+    """Clip of rank r (BASELINE configs[3]): frame t is drawn from seed 1000*r + t."""
+    frames = [synth.make_inputs(spec, 1, H, W, 1000 * r + t) for t in range(T)]
+    labels = torch.stack([f[0] for f in frames])          # [T,1,22,H,W]
+    dains = torch.stack([f[1] for f in frames])           # [T,1,3,H,W]
+    key = frames[0][2]                                    # the key frame the chain starts from
+    return key, labels, dains
+
+
+def main():
+    args = parse_args()
+    from render_in_between_amd import distributed as ribdist
+    if args.gpus > 1 and not ribdist.is_rank_process():
+        # not a rank yet: start one fresh process per GPU (nothing in THIS process has touched the GPU) and hand
+        # back their exit code; rank 0 prints the JSON line on the shared stdout
+        sys.exit(ribdist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import render_in_between_amd as rib
-    from render_in_between_amd import synth, distributed as ribdist
+    from render_in_between_amd import synth
 
-    # RIB_BENCH_DEVICE / RIB_DIST_BACKEND exist only to exercise the multi-rank path on a 1-GPU box
+    # RIB_BENCH_DEVICE / RIB_DIST_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box
     # (all ranks on one device, gloo instead of RCCL); the driver's multi-GPU runs use neither.
     dev_index = int(os.environ.get("RIB_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
@@ -85,9 +123,7 @@ def main():
         G.load_state_dict(sd)
     if world > 1:
         t_bcast_ms = ribdist.broadcast_weights(G, src=0)
-
-    # per-rank synthetic inputs (rank r renders its own frames)
-    label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 1000 * rank)]
+    blob_sum = ribdist.blob_checksum(G.export_weights())
 
     # extra in-flight lanes: clones of the generator (same folded weight blob) on their own streams
     lanes = [(G, torch.cuda.current_stream(dev))]
@@ -99,26 +135,36 @@ def main():
         torch.cuda.synchronize(dev)
 
     frames_per_step = B
-    if args.mode == "chain":
+    if args.mode == "clips":
+        if B != 1:
+            raise SystemExit("--mode clips renders batch-1 clips")
         T = args.frames
-        frames_per_step = B * T
-        labels = label.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
-        dains = fake.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+        frames_per_step = T
+        key, labels, dains = [t.to(dev) for t in clip_inputs(spec, synth, rank, T, H, W)]
 
         def step(i=0):
             g, st = lanes[i % len(lanes)]
             with torch.cuda.stream(st):
-                return g.chain(prev, labels, dains, want_all=False)[2]
+                return g.chain(key, labels, dains, want_all=False)[2]
     else:
-        def step(i=0):
-            g, st = lanes[i % len(lanes)]
-            with torch.cuda.stream(st):
-                img, mask = g(label, None, fake, prev)
-                return g.blend(img, mask, fake)
+        # per-rank synthetic inputs (rank r renders its own frames)
+        label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 1000 * rank)]
+        if args.mode == "chain":
+            T = args.frames
+            frames_per_step = B * T
+            labels = label.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+            dains = fake.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
 
-    def log(msg):
-        if rank == 0:
-            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+            def step(i=0):
+                g, st = lanes[i % len(lanes)]
+                with torch.cuda.stream(st):
+                    return g.chain(prev, labels, dains, want_all=False)[2]
+        else:
+            def step(i=0):
+                g, st = lanes[i % len(lanes)]
+                with torch.cuda.stream(st):
+                    img, mask = g(label, None, fake, prev)
+                    return g.blend(img, mask, fake)
 
     log("weights ready, warming up")
     for i in range(max(args.warmup, len(lanes))):
@@ -131,6 +177,7 @@ def main():
     for i in range(args.steps):
         out = step(i)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0           # this rank's own time (per-rank frames/s below)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -142,8 +189,29 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     fps = world * frames_per_step * args.steps / dt
 
+    # ---- control-plane exchange (after the timed region): per-rank rates, blob checksums, replica check ----
+    per_rank_fps = ribdist.gather_rows(torch.tensor([frames_per_step * args.steps / dt_rank], dtype=torch.float64, device=dev), rank, world).flatten().tolist()
+    sums = ribdist.gather_rows(torch.tensor([blob_sum], dtype=torch.int64, device=dev), rank, world).flatten().tolist()
+    replica = None
+    if args.mode == "clips":
+        last = ribdist.gather_rows(out[-1].contiguous(), rank, world)      # every rank's last fused frame, [world,1,3,H,W]
+        if rank == 0:
+            # rank 0 (whose weights came from load_state_dict, not from the broadcast) renders every rank's clip
+            # itself, as a 1-GPU run would, and compares the last frames bit for bit
+            eq = []
+            for r in range(world):
+                if r == 0:
+                    mine = out[-1]
+                else:
+                    k_r, l_r, d_r = [t.to(dev) for t in clip_inputs(spec, synth, r, args.frames, H, W)]
+                    mine = G.chain(k_r, l_r, d_r, want_all=False)[2][-1]
+                eq.append(bool(torch.equal(mine, last[r])))
+            replica = {"clips_checked": world, "last_frame_bit_equal_to_single_gpu_run": eq, "all_equal": all(eq)}
+            log("replica check: %s" % eq)
+
     if rank != 0:
         if world > 1:
+            torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
 
@@ -151,34 +219,51 @@ def main():
     # ---- roofline of the dominant kernel class: profiling pass (not in the timed region) ----
     flops = G.forward_flops(B, H, W)
     G.profile_begin()
-    nprof = 5
+    nprof = 5 if args.mode == "frame" else 1
     for _ in range(nprof):
         step()
     prof = G.profile_collect()
-    if args.mode == "chain":
+    if args.mode != "frame":
         nprof = nprof * args.frames          # per-forward averages
     conv_ms = prof["igemm"]["ms"] / nprof
     conv_tflops = flops["igemm"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     spade_ms = prof["spade"]["ms"] / nprof
     classes = {k: {"launches_per_step": v["launches"] / nprof, "ms_per_step": v["ms"] / nprof} for k, v in prof.items()}
+    # executed matrix work: the three mask-network upsample convolutions run as 2x2 phase convolutions, 4/9 of their
+    # nine-tap count; everything else executes what it is priced at (channel padding not counted)
+    executed = 0.0
+    for info in G.launch_info(B, H, W):
+        if info["class"] == 0:
+            executed += info["flops"] * (4.0 / 9.0 if "ups1" in info["tile"] else 1.0)
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py:
-    # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); bench.py itself cannot read counters
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp) and (B, H, W) == (1, 512, 512):
-        with open(tp) as f:
-            traffic = json.load(f)["classes"]["igemm"]["hbm_bytes_per_launch"]
+    # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes); bench.py itself cannot read counters,
+    # so this is a pointer to the committed measurement of the same workload, NOT measured in this run
+    traffic = traffic_step = traffic_src = None
+    for tag in ("r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+        if os.path.exists(tp) and (B, H, W) == (1, 512, 512) and args.dtype == "f32":
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic = tj["classes"]["igemm"]["hbm_bytes_per_launch"]
+            traffic_step = tj["total_hbm_bytes_per_step"]
+            traffic_src = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_ops.py; not measured in this run)" % tag
+            break
+    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     roofline = {
         "bound": "mfma",
         # the convolution class: k_igemm on the matrix cores; at fp32 the 1..4-channel heads (conv_img, conv_mask.0:
         # 2 launches, 0.5 GFLOP) run as k_conv_small on the vector ALUs.  "algorithmic" = nine-tap 2*MAC count of
         # SURVEY 8(d); the three upsample convolutions execute 4/9 of theirs (phase decomposition)
-        "kernel": "convolution class: k_igemm, fp32 MFMA implicit GEMM (%d launches/step incl. 2 k_conv_small heads)" % int(prof["igemm"]["launches"] / nprof),
-        "achieved": conv_tflops, "peak": PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": conv_tflops / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
+        "kernel": "convolution class: k_igemm, %s MFMA implicit GEMM (%d launches/step incl. 2 k_conv_small heads)" % (args.dtype, int(prof["igemm"]["launches"] / nprof)),
+        "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
+        "frac": conv_tflops / peak,
         "avg_launch_us": conv_ms * 1e3 / max(1.0, prof["igemm"]["launches"] / nprof),
         "algorithmic_gflop_per_step": flops["igemm"] / 1e9,
+        "executed_gflop_per_step": executed / 1e9,
+        "executed_tflops": executed / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
         "traffic": traffic,
+        "traffic_bytes_per_step_all_classes": traffic_step,
+        "traffic_source": traffic_src,
         "classes": classes,
         "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) * (frames_per_step / B) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
@@ -191,7 +276,8 @@ def main():
     if not args.no_cpu_baseline and args.mode == "frame" and world == 1:   # rank 0 at N=1 only
         from oracle import generator_ref
         R = generator_ref.RefGenerator(spec, sd)
-        torch.set_num_threads(min(16, os.cpu_count() or 1))   # 16 threads is the fastest setting on the 256-CPU GPU box (tools/cpu_threads.py sweep: 8/16/32/64/128)
+        threads = min(16, os.cpu_count() or 1)   # 16 threads is the fastest setting on the 256-CPU GPU box (tools/cpu_threads.py sweep: 8/16/32/64/128)
+        torch.set_num_threads(threads)
         lc, fc, pc = label.cpu(), fake.cpu(), prev.cpu()
         oimg, omask = R(lc, None, fc, pc)                       # warm-up + parity reference
         log("cpu oracle warm-up frame done (%d threads)" % torch.get_num_threads())
@@ -200,32 +286,46 @@ def main():
                   "max_abs_mask": float((mask.cpu() - omask).abs().max()),
                   "tolerance": 1e-3 if args.dtype == "f32" else None}
         ts = []
-        for _ in range(args.cpu_frames):
+        reps = max(5, args.cpu_frames)
+        for _ in range(reps):
             t1 = time.perf_counter()
             oi, om = R(lc, None, fc, pc)
             generator_ref.blend(oi, om, fc)
             ts.append(time.perf_counter() - t1)
         med = sorted(ts)[len(ts) // 2]
         cpu = {"value": B / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "%d forward+blend passes of the same %dx%d B=%d fp32 workload through the CPU oracle "
-                         "(PyTorch restatement validated against the imported reference), median" % (args.cpu_frames, H, W, B)}
+               "threads": torch.get_num_threads(), "host_cores": os.cpu_count(), "cpu_model": cpu_model_name(), "reps": reps,
+               "seconds_per_frame": {"median": med, "min": min(ts), "max": max(ts)},
+               "sample": "%d forward+blend passes (after 1 warm-up) of the same %dx%d B=%d fp32 workload through the CPU oracle "
+                         "(PyTorch restatement validated against the imported reference), median; `cores` = threads used"
+                         % (reps, H, W, B)}
 
-    dt_name = "fp32" if args.dtype == "f32" else "bf16 matrix-core operands (fp32 accumulate / statistics / storage)"
+    dt_name = "fp32" if args.dtype == "f32" else "bf16"
+    if args.mode == "frame":
+        workload = "%dx%d single-frame generator fwd + blend, batch=%d, %s" % (H, W, B, dt_name)
+    elif args.mode == "chain":
+        workload = "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, %s" % (H, W, args.frames, B, dt_name)
+    else:
+        workload = "%dx%d, %d independent %d-frame clips sharded over %d GPU(s) (one clip per rank and step, seeds 1000*rank+t), %s" % (
+            H, W, world, args.frames, world, dt_name)
     line = {
-        "metric": "rendered frames/sec at 512x512 (generator forward + blend, device-resident)",
+        "metric": "rendered frames/sec at %dx%d (generator forward + blend, device-resident)" % (H, W),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("%dx%d single-frame generator fwd + blend, batch=%d, %s" % (H, W, B, dt_name) if args.mode == "frame" else
-                                "%dx%d autoregressive %d-frame segment (prev <- fused frame on device), batch=%d, %s" % (H, W, args.frames, B, dt_name))
-                               + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
-                   "frames_per_step_per_gpu": B, "parallelism": "frames sharded over %d GPU(s), one RCCL weight broadcast" % world,
+        "config": {"workload": workload + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
+                   "frames_per_step_per_gpu": frames_per_step,
+                   "parallelism": "%s sharded over %d GPU(s), one RCCL weight broadcast, no per-frame collective" % ("clips" if args.mode == "clips" else "frames", world),
                    "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1,
-                   "frames_in_flight_per_gpu": len(lanes)},
+                   "frames_in_flight_per_gpu": len(lanes),
+                   "per_rank_frames_per_s": per_rank_fps,
+                   "blob_checksum": sums[0], "blob_checksum_equal_on_all_ranks": len(set(sums)) == 1,
+                   "replica_check": replica},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -1408,7 +1408,8 @@ int rib_finalize_weights(rib_handle* h) {
     HIP_TRY(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->weights_ready = true;
   }
-  for (auto& t : h->tensors) { std::vector<float>().swap(t.data); }   // host copies no longer needed
+  // the host copies stay (138 MB at HSM.yaml's size): a later rib_set_tensor of a SUBSET of the tensors followed by
+  // rib_finalize_weights (load_state_dict(strict=False), a fine-tuned head) folds the new values with the old ones
   return RIB_OK;
 }
 
@@ -1418,6 +1419,7 @@ int rib_export_weights(rib_handle* h, void* dst, size_t bytes, void* hip_stream)
   int rc = check_ready(h);
   if (rc) return rc;
   if (!dst || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_export_weights: size mismatch");
+  HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpyAsync(dst, h->d_blob, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
   return RIB_OK;
 }
@@ -1425,6 +1427,8 @@ int rib_export_weights(rib_handle* h, void* dst, size_t bytes, void* hip_stream)
 int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_stream) {
   if (!h) return RIB_ERR_INVALID;
   if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
+  if (h->device < 0) return fail(h, RIB_ERR_INVALID, "rib_import_weights: host-only handle");
+  HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpyAsync(h->d_blob, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
   h->weights_ready = true;
   return RIB_OK;
@@ -1463,6 +1467,7 @@ int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const fl
 int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const float* mask,
               const float* dain, float* fuse, void* hip_stream) {
   if (!h || !img || !mask || !dain || !fuse) return RIB_ERR_INVALID;
+  if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   const size_t total = (size_t)B * C * H * W;
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(k_blend, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, mask, dain, fuse, C, H * W, total);
@@ -1472,6 +1477,7 @@ int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const
 
 int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, uint8_t* out, void* hip_stream) {
   if (!h || !img || !out) return RIB_ERR_INVALID;
+  if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   const size_t total = (size_t)B * C * H * W;
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, out, C, H * W, total);
@@ -1481,6 +1487,7 @@ int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, ui
 
 int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const float* flow, float* out, void* hip_stream) {
   if (!h || !img || !flow || !out) return RIB_ERR_INVALID;
+  if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(k_warp, dim3((H * W + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;

@@ -15,7 +15,10 @@ Differences from the reference, none of which change a pixel:
     per frame with scipy / numpy loops on the host (evaluator.py:221-229);
   * file decode / encode runs on a thread pool, the quantised frames of a segment come back in
     one pinned device-to-host copy, and the three phases are pipelined over segments (SURVEY 8 row
-    f-1: at hundreds of frames/s the per-frame .cpu() + PNG encode of evaluator.py:260-266 is the wall).
+    f-1: at hundreds of frames/s the per-frame .cpu() + PNG encode of evaluator.py:260-266 is the wall);
+  * multi-GPU: the independent units (the segments between key frames, evaluator.py:240-244, over all clips,
+    :169-171) are dealt round-robin to the ranks of the process group (distributed.shard_units); every rank
+    decodes, renders and writes only its own frames, with no communication after the weight broadcast.
 """
 from __future__ import annotations
 
@@ -82,10 +85,20 @@ class Evaluator:
         """(generator, stream) pairs for concurrent segments; None for single-lane / non-native models."""
         if self.lanes <= 1 or nsegs <= 1 or not hasattr(model, "clone"):
             return None
-        if getattr(self, "_lane_cache", None) is None or self._lane_cache[0] is not model:
+        ver = getattr(model, "weights_version", 0)
+        cache = getattr(self, "_lane_cache", None)
+        if cache is None or cache[0] is not model:
             gens = [model] + [model.clone() for _ in range(self.lanes - 1)]
-            self._lane_cache = (model, [(g, torch.cuda.Stream(device=model.device)) for g in gens])
-        return self._lane_cache[1][:max(1, min(self.lanes, nsegs))]
+            self._lane_cache = cache = (model, [(g, torch.cuda.Stream(device=model.device)) for g in gens], ver)
+        elif cache[2] != ver:
+            # the model got new weights (load_state_dict / import_weights) since the lanes were cloned: refresh the
+            # clones' blobs, or segments would alternate between old and new weights
+            blob = model.export_weights()
+            for g, _ in cache[1][1:]:
+                g.import_weights(blob)
+            torch.cuda.current_stream(model.device).synchronize()
+            self._lane_cache = cache = (model, cache[1], ver)
+        return cache[1][:max(1, min(self.lanes, nsegs))]
 
     # ---- per-frame host pre-processing (evaluator.py:205-235) --------------------------------
     def load_image(self, path):
@@ -129,15 +142,26 @@ class Evaluator:
 
     # ---- the driver ------------------------------------------------------------------------------
     @torch.no_grad()
-    def evaluate_from_folder(self, model, train_dir, dain_dir, pose_dir, save_dir, gt_dir=None, gen_vid=False):
-        """Pipelined over segments: file decode (thread pool) -> label rasterisation + autoregressive chain +
+    def evaluate_from_folder(self, model, train_dir, dain_dir, pose_dir, save_dir, gt_dir=None, gen_vid=False,
+                             rank=None, world=None):
+        """rank / world: this process's share of the independent units (default: the torch.distributed process
+        group when one is initialised, else everything).  Returns the frames THIS rank wrote.
+        Pipelined over segments: file decode (thread pool) -> label rasterisation + autoregressive chain +
         quantise on a lane's stream -> one pinned device-to-host copy per segment -> PNG encode (thread pool).
         The main thread only enqueues; decode of later frames and encode of finished segments overlap the
         GPU work (run back to back, the three phases cost about the same: 0.21 / 0.24 / 0.23 s for a
         65-frame 512x512 clip, profiles/r01_raster_driver.json)."""
         from PIL import Image
+        if gen_vid:
+            # the reference also writes <save_dir>/<clip>.mp4 (evaluator.py:267-269, utils.make_video); not built, and
+            # silently ignoring the flag would drop an output the caller asked for
+            raise NotImplementedError("evaluate_from_folder: gen_vid is not supported")
+        if rank is None or world is None:
+            import torch.distributed as dist
+            rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
         model.eval()
         written: List[str] = []
+        unit = 0                                              # running index of independent units over all clips
         tm = self.timings = {"load": 0.0, "rasterise": 0.0, "generate": 0.0, "save": 0.0, "frames": 0}
         if self._pool is None:
             self._pool = ThreadPoolExecutor(self.io_threads)          # decode + encode workers
@@ -146,6 +170,13 @@ class Evaluator:
         native = hasattr(model, "chain") and hasattr(model, "quantise")
         gpu_labels = native and self.label_fn is None and hasattr(model, "rasterise")
         kw = {} if self.png_compress_level is None else {"compress_level": int(self.png_compress_level)}
+        sizes = {}
+
+        def image_size(path):                                 # header only; the keypoints scale with THIS image (below)
+            if path not in sizes:
+                with Image.open(path) as im:
+                    sizes[path] = im.size
+            return sizes[path]
 
         def save_host(x, name):                               # utils/utils.py:129-142 on the host
             a = np.transpose(x[0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
@@ -170,7 +201,19 @@ class Evaluator:
             seq_len = (len(image_list) - 1) * sample_rate + 1
             names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
 
+            gtlist = _list(os.path.join(gt_dir, sub), ("jpg", "png")) if gt_dir is not None else None
             keys, segs = split_segments(seq_len, sample_rate)
+            # this rank's share: a segment is one unit and brings the key frame it starts from along (that frame is
+            # decoded for the chain anyway); a key frame without a segment (the last one) is a unit of its own
+            first_of = {k: si for si, (k, _) in enumerate(segs)}
+            my_segs, my_keys = [], []
+            for k in keys:
+                if unit % world == rank:
+                    my_keys.append(k)
+                    if k in first_of:
+                        my_segs.append(first_of[k])
+                unit += 1
+            segs = [segs[si] for si in my_segs]
             # native path: every segment gets one pinned staging buffer that the decode workers fill in place
             # (no stack on the launch thread, and the upload from pinned memory is asynchronous)
             stage, slot = {}, {}
@@ -180,17 +223,23 @@ class Evaluator:
                     for j, i in enumerate(frames):
                         slot[i] = (si, j)
 
-            def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, sample_rate=sample_rate, stage=stage, slot=slot):
-                dain, osz = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
+            def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
+                dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
                 if i in slot:
                     stage[slot[i][0]][slot[i][1]].copy_(dain)
                     dain = None
-                gt = self.load_image(image_list[i // sample_rate])[0] if i % sample_rate == 0 else None
-                pose = self.load_pose(pose_list[i], osz)
+                # evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame
+                # of its segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale
+                # by its size, not by the DAIN frame's
+                ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
+                gt = self.load_image(ref_img)[0] if i % sample_rate == 0 else None
+                pose = self.load_pose(pose_list[i], image_size(ref_img))
                 if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
                     pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
                 return dain, gt, pose
-            loads = [pool.submit(load, i) for i in range(seq_len)]                 # FIFO: earlier frames decode first
+            need = sorted(set(my_keys) | {i for _, frames in segs for i in frames})
+            loads = {i: pool.submit(load, i) for i in need}                        # FIFO: earlier frames decode first
+            keys = my_keys
             lanes = self._lanes(model, len(segs)) if native else None
             futs = {}
             for k in keys:                                                         # key frames pass through (evaluator.py:240-244)
@@ -257,10 +306,12 @@ class Evaluator:
                     for t, i in enumerate(frames):
                         futs[i] = pool.submit(save_host, outs[t], names[i])
             clip_outputs.append((names, futs))
-            tm["frames"] += seq_len
+            tm["frames"] += len(futs)
         t5 = time.perf_counter()
         for names, futs in clip_outputs:                                           # frame order, as the reference writes them
             for i, name in enumerate(names):
+                if i not in futs:
+                    continue                                                       # another rank's frame
                 f = futs[i]
                 res = f[0].result()[f[1]] if isinstance(f, tuple) else f.result()
                 assert res == name

@@ -67,6 +67,8 @@ class Generator:
         _native.check(h, self._lib.rib_set_compute_dtype(h, 1 if compute_dtype == "bf16" else 0))
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.training = False
+        self.weights_version = 0        # bumped by load_state_dict / import_weights (Evaluator's lane clones follow it)
+        self._warned_copy = False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -126,6 +128,7 @@ class Generator:
             _native.check(self._h, self._lib.rib_set_tensor(self._h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), dims))
         with torch.cuda.device(self.device):
             _native.check(self._h, self._lib.rib_finalize_weights(self._h))
+        self.weights_version += 1
         return self
 
     # ---- multi-GPU weight hand-off (one RCCL broadcast of the folded blob) -----------------
@@ -151,6 +154,7 @@ class Generator:
     def import_weights(self, buf: torch.Tensor):
         assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
         _native.check(self._h, self._lib.rib_import_weights(self._h, _ptr(buf), buf.numel() * 4, self._stream()))
+        self.weights_version += 1
         return self
 
     # ---- forward ----------------------------------------------------------------------------
@@ -183,9 +187,17 @@ class Generator:
             raise ValueError("%s must be a [B,%d,H,W] tensor, got %s" % (name, ch, tuple(getattr(t, "shape", ()))))
         if shape is not None and (t.shape[0], t.shape[2], t.shape[3]) != shape:
             raise ValueError("%s has shape %s, expected B,H,W = %s" % (name, tuple(t.shape), shape))
-        if t.device != self.device:
-            t = t.to(self.device)
-        return t.to(torch.float32).contiguous()
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            if not self._warned_copy:
+                # the reference driver keeps results['fuse'] on the CPU (evaluator.py:252): fed to this object unchanged
+                # that is a host-to-device copy per frame; say so once instead of hiding it
+                import warnings
+                warnings.warn("Generator: %s arrived as %s/%s%s and is copied to %s float32 contiguous on every call; keep "
+                              "the tensors on the GPU (or use Generator.chain) to avoid a per-frame copy"
+                              % (name, t.device, str(t.dtype).replace("torch.", ""), "" if t.is_contiguous() else "/strided", self.device))
+                self._warned_copy = True
+            t = t.to(self.device, torch.float32)
+        return t.contiguous()
 
     def __call__(self, label, label_prev, img_fake, img_prev):
         """img_final, mask = G(label, label_prev, img_fake, img_prev)
@@ -315,3 +327,14 @@ class Generator:
 
     def num_launches(self, B, H, W):
         return self._lib.rib_num_launches(self._h, B, H, W)
+
+    def launch_info(self, B, H, W):
+        """The launch plan of a shape: [{name, class (index into _native.KC_NAMES), grid, tile, flops}]."""
+        self._workspace(B, H, W)                       # pins the tuned choices of this shape first
+        buf = C.create_string_buffer(512)
+        out = []
+        for i in range(self._lib.rib_num_launches(self._h, B, H, W)):
+            _native.check(self._h, self._lib.rib_debug_launch_info(self._h, B, H, W, i, buf, 512))
+            name, kclass, grid, tile, flops = buf.value.decode().split("|")
+            out.append({"name": name, "class": int(kclass), "grid": grid, "tile": tile, "flops": float(flops)})
+        return out

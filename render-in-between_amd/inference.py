@@ -6,6 +6,11 @@
 
 Unlike the reference it builds only what inference needs: the generator (no discriminator, VGG
 perceptual loss, optimisers or h5 dataset; PGNR/models/trainer.py:61-113).
+
+Multi-GPU (new; the reference is single-device): `--gpus N` starts N ranks, one per GPU (or launch it under
+torch.distributed.run yourself).  Rank 0 reads and folds the checkpoint, the folded blob reaches the other ranks in
+ONE RCCL broadcast, and the independent segments between key frames (PGNR/models/evaluator.py:240-244) of all clips
+(:169-171) are dealt round-robin to the ranks; every rank writes its own frames into the same output tree.
 """
 import argparse
 import os
@@ -22,33 +27,53 @@ import render_in_between_amd as rib                                   # noqa: E4
 from render_in_between_amd.evaluator import Evaluator                 # noqa: E402
 
 
-def load_generator(config, device=None):
-    """trainer.net_G with its checkpoint (PGNR/models/trainer.py:61,67; utils/utils.py:107-119)."""
+def load_generator(config, device=None, rank=0, world=1):
+    """trainer.net_G with its checkpoint (PGNR/models/trainer.py:61,67; utils/utils.py:107-119).  With several
+    ranks only rank 0 touches the file; the others receive the folded weights (distributed.broadcast_weights)."""
     net_G = rib.Generator(config.gen, device=device)
     path = config.model_pretrain_G
-    if os.path.isfile(path):
+    if not os.path.isfile(path):
+        raise ValueError("=> No checkpoint found at '{}'".format(path))
+    if rank == 0:
         checkpoint = torch.load(path, map_location="cpu")
         print("=> Loaded checkpoint '{}'".format(path))
-    else:
-        raise ValueError("=> No checkpoint found at '{}'".format(path))
-    net_G.load_state_dict(checkpoint)
+        net_G.load_state_dict(checkpoint)
+    if world > 1:
+        from render_in_between_amd import distributed as ribdist
+        ms = ribdist.broadcast_weights(net_G, src=0)
+        if rank == 0:
+            print("=> weights broadcast to {} ranks in {:.1f} ms".format(world, ms))
     return net_G
 
 
 def main(opts):
+    from render_in_between_amd import distributed as ribdist
+    if opts.gpus > 1 and not ribdist.is_rank_process():
+        # not a rank yet: start one process per GPU (before anything here touches the GPU) and hand back their exit code
+        sys.exit(ribdist.self_launch(os.path.abspath(__file__), sys.argv[1:], opts.gpus))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     random.seed(opts.seed)
     np.random.seed(opts.seed)
     torch.manual_seed(opts.seed)
     config = rib.get_config(opts.config)
     config.out_dir = opts.save_dir
     config.eval_dir = opts.save_dir
-    net_G = load_generator(config)
+    device = None
+    if world > 1:
+        device = torch.device("cuda", int(os.environ.get("RIB_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        torch.cuda.set_device(device)
+        ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"))
+    net_G = load_generator(config, device, rank, world)
     evaluator = Evaluator(config)
     train_dir = os.path.join(opts.input_dir, "inputs")
     dain_dir = os.path.join(opts.input_dir, "DAIN")
     pose_dir = os.path.join(opts.input_dir, "Predict_motion")
     save_dir = os.path.join(opts.save_dir, "Generated_frames")
-    evaluator.evaluate_from_folder(net_G, train_dir, dain_dir, pose_dir, save_dir, gt_dir=None, gen_vid=False)
+    written = evaluator.evaluate_from_folder(net_G, train_dir, dain_dir, pose_dir, save_dir, gt_dir=None, gen_vid=False)
+    if world > 1:
+        print("[rank {}/{}] wrote {} frames".format(rank, world, len(written)))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
@@ -57,4 +82,5 @@ if __name__ == "__main__":
     parser.add_argument("--save-dir", type=str, default="../example", help="outputs path")
     parser.add_argument("--input-dir", type=str, required=True, help="input low FPS frames and pose input")
     parser.add_argument("--seed", type=int, default=123)
+    parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")
     main(parser.parse_args())

@@ -18,6 +18,37 @@ def _free_port():
     return p
 
 
+def _shard_worker(rank, world, port, root, q):
+    """The product's multi-GPU path on CPU: Evaluator.evaluate_from_folder under a world-2 process group deals the
+    segments of all clips to the ranks; the generator is the CPU oracle behind the reference's call protocol."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ribdist.init_process_group("gloo")
+    import render_in_between_amd as rib
+    from render_in_between_amd import evaluator as ev, synth
+    from oracle import generator_ref
+    from tests.test_driver import MID_CFG, oracle_labels
+    torch.set_num_threads(2)
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48, gauss_sigma=5,
+                       skeleton_thres=0.001, foot_thres=0.001)
+    spec = rib.GenSpec.from_cfg(cfg.gen)
+    R = generator_ref.RefGenerator(spec, synth.make_state_dict(spec, 2))
+
+    class Model:
+        def eval(self):
+            return self
+
+        def __call__(self, label, label_prev, dain, prev):
+            return R(label, label_prev, dain, prev)
+
+    E = ev.Evaluator(cfg, label_fn=oracle_labels)
+    written = E.evaluate_from_folder(Model(), os.path.join(root, "inputs"), os.path.join(root, "DAIN"),
+                                     os.path.join(root, "Predict_motion"), os.path.join(root, "sharded"))
+    rows = ribdist.gather_rows(torch.tensor([float(len(written)), float(rank)]), rank, world)
+    q.put((rank, [os.path.basename(w) for w in written], rows.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     ribdist.init_process_group("gloo")
@@ -60,3 +91,90 @@ def test_shard_units_edge_cases():
     assert ribdist.shard_units(0, 0, 4) == []
     assert ribdist.shard_units(3, 2, 8) == [2] and ribdist.shard_units(3, 3, 8) == [] and ribdist.shard_units(3, 5, 8) == []
     assert sum(len(ribdist.shard_units(32, r, 8)) for r in range(8)) == 32
+
+
+def test_evaluator_shards_segments_over_ranks(tmp_path):
+    """world 2 (gloo): every frame is written exactly once, by the rank that owns its segment, and the frames equal
+    a single-process run's bit for bit (segments are independent: PGNR/models/evaluator.py:240-244)."""
+    import numpy as np
+    from PIL import Image
+    import render_in_between_amd as rib
+    from render_in_between_amd import evaluator as ev, synth
+    from oracle import generator_ref
+    from tests.test_driver import MID_CFG, _write_example, oracle_labels
+    root = str(tmp_path)
+    n = _write_example(root, n_key=4, rate=2, H=32, W=48)            # 7 frames: 4 key frames, 3 one-frame segments
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, rows0), (_, w1, rows1) = res
+    assert rows0 == rows1 == [[float(len(w0)), 0.0], [float(len(w1)), 1.0]]     # gather_rows: every rank sees every row
+    assert sorted(w0 + w1) == ["f%03d.png" % i for i in range(n)] and not set(w0) & set(w1)
+    # units: key 0 + its segment -> rank 0, key 2 + segment -> rank 1, key 4 + segment -> rank 0, key 6 (no segment) -> rank 1
+    assert w0 == ["f000.png", "f001.png", "f004.png", "f005.png"] and w1 == ["f002.png", "f003.png", "f006.png"]
+    # single-process run of the same folder
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48, gauss_sigma=5,
+                       skeleton_thres=0.001, foot_thres=0.001)
+    spec = rib.GenSpec.from_cfg(cfg.gen)
+    R = generator_ref.RefGenerator(spec, synth.make_state_dict(spec, 2))
+
+    class Model:
+        def eval(self):
+            return self
+
+        def __call__(self, *a):
+            return R(*a)
+
+    one = ev.Evaluator(cfg, label_fn=oracle_labels).evaluate_from_folder(
+        Model(), os.path.join(root, "inputs"), os.path.join(root, "DAIN"), os.path.join(root, "Predict_motion"),
+        os.path.join(root, "single"), rank=0, world=1)
+    assert len(one) == n
+    for f in one:
+        a = np.asarray(Image.open(f))
+        b = np.asarray(Image.open(f.replace(os.sep + "single" + os.sep, os.sep + "sharded" + os.sep)))
+        assert np.array_equal(a, b), f
+
+
+def test_self_launch_command_and_rank_detection(monkeypatch):
+    cmd = ribdist.launch_command("/x/bench.py", ["--gpus", "8", "--mode", "clips"], 8, port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--mode", "clips"]
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    assert not ribdist.is_rank_process()
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "3")
+    assert ribdist.is_rank_process()
+    assert 1024 < ribdist.free_port() < 65536
+    # world 1: gather_rows is the identity with a leading axis, no process group needed
+    t = torch.arange(6, dtype=torch.int64).reshape(2, 3)
+    assert torch.equal(ribdist.gather_rows(t, 0, 1), t[None])
+
+
+def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside torch.distributed.run must spawn the ranks as children (and never build a
+    Generator in the parent); under torch.distributed.run it must not spawn."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rib_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(ribdist, "self_launch", lambda script, argv, n: calls.append((script, list(argv), n)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "4", "--mode", "clips", "--steps", "2"])
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and calls == [(os.path.join(root, "bench.py"), ["--gpus", "4", "--mode", "clips", "--steps", "2"], 4)]
+    a = bench.parse_args(["--gpus", "8", "--mode", "clips"])
+    assert a.frames == 32 and a.size == 512 and a.batch == 1 and a.cpu_frames >= 5

@@ -146,6 +146,45 @@ def test_evaluate_from_folder_matches_oracle_loop(tmp_path):
                                                os.path.join(root, "Predict_motion"), out + "2")
 
 
+def test_gt_dir_and_keypoint_scaling_follow_the_reference(tmp_path):
+    """evaluator.py:205-219: with a gt_dir the key frames / chain starts are gtlist[i]; the keypoints are resized
+    together with the key (or gt) image, i.e. they scale by ITS size, not by the DAIN frame's; gen_vid is refused."""
+    from PIL import Image
+    root = str(tmp_path)
+    n = _write_example(root, n_key=2, rate=2, H=32, W=48)
+    rng = np.random.default_rng(9)
+    os.makedirs(os.path.join(root, "gt", "clipA"))
+    for i in range(n):                      # ground-truth frames at TWICE the model size: joints must halve
+        Image.fromarray(rng.integers(0, 255, (64, 96, 3), dtype=np.uint8)).save(os.path.join(root, "gt", "clipA", "g%03d.png" % i))
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48, gauss_sigma=5,
+                       skeleton_thres=0.001, foot_thres=0.001)
+    spec = rib.GenSpec.from_cfg(cfg.gen)
+    R = generator_ref.RefGenerator(spec, synth.make_state_dict(spec, 2))
+    seen = []
+
+    class Model:
+        def eval(self):
+            return self
+
+        def __call__(self, label, label_prev, dain, prev):
+            seen.append((label.clone(), prev.clone()))
+            return R(label, label_prev, dain, prev)
+
+    E = ev.Evaluator(cfg, label_fn=oracle_labels)
+    dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
+    written = E.evaluate_from_folder(Model(), *dirs, os.path.join(root, "o"), gt_dir=os.path.join(root, "gt"))
+    assert len(written) == n == 3 and len(seen) == 1
+    g0, size0 = E.load_image(os.path.join(root, "gt", "clipA", "g000.png"))
+    assert size0 == (96, 64)
+    assert torch.equal(seen[0][1], g0.unsqueeze(0))                       # the chain starts from gtlist[0], not inputs/0000.png
+    want = oracle_labels([E.load_pose(os.path.join(root, "Predict_motion", "clipA", "f001_keypoints.json"), (96, 64))], 32, 48)
+    assert torch.equal(seen[0][0], want)                                  # joints scaled by the gt image's size (x0.5)
+    assert np.array_equal(np.asarray(Image.open(written[2])),
+                          generator_ref.quantise_uint8(E.load_image(os.path.join(root, "gt", "clipA", "g002.png"))[0].unsqueeze(0)))
+    with pytest.raises(NotImplementedError):
+        E.evaluate_from_folder(Model(), *dirs, os.path.join(root, "o2"), gen_vid=True)
+
+
 def test_inference_cli_surface():
     import importlib.util
     p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "render-in-between_amd", "inference.py")

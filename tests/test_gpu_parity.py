@@ -501,3 +501,101 @@ def test_full_size_properties_512():
     back = (q.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
     q2 = G.quantise(back + 1e-4)      # already on the uint8 grid (nudged off the truncation edge): unchanged
     assert torch.equal(q, q2)
+
+
+# ---- round 2: the configurations of BASELINE.json that had no GPU test, and the reference-pinned quantiser ----
+def test_quantise_equals_the_reference_bytes(golden_dir):
+    """rib_quantise vs the bytes the reference's own tensor2images produced (tests/golden/quant_ref.npz, made by
+    make_golden_quant.py from PGNR/utils/utils.py:122-147): bit for bit on the reference's chain frame and on a tensor
+    of knife-edge values (every k/255 edge and its fp32 neighbours, out-of-range values, +-inf)."""
+    spec, sd, G = build("full", 0)
+    g = np.load(os.path.join(golden_dir, "quant_ref.npz"))
+    c = np.load(os.path.join(golden_dir, "chain3_128.npz"))
+    q = G.quantise(torch.from_numpy(c["fuse_last"])).cpu().numpy()[0]
+    assert q.dtype == np.uint8 and np.array_equal(q, g["chain_last_quant"])
+    e = G.quantise(torch.from_numpy(g["edge_in"])).cpu().numpy()[0]
+    assert np.array_equal(e, g["edge_quant"]), int((e != g["edge_quant"]).sum())
+
+
+def test_config3_32_frame_chain_512_fp32_and_bf16_against_the_oracle_loop():
+    """BASELINE configs[2]: one 32-frame autoregressive segment at 512x512, batch 1 (prev <- fused frame on the device),
+    against the CPU oracle's frame-by-frame loop (evaluator.py:238-262).  fp32: the north star's 1e-3 must hold on the
+    LAST frame, after 32 steps of feedback.  bf16 mode: its own stated bound (there is no reference counterpart)."""
+    from oracle import generator_ref
+    spec, sd, G = build("full", 0)
+    H = W = 512
+    T = 32
+    key = synth.smooth_image(spec, 1, H, W, 3100)
+    labels = torch.stack([synth.make_inputs(spec, 1, H, W, 3100 + t)[0] for t in range(T)])
+    dains = torch.stack([synth.smooth_image(spec, 1, H, W, 3200 + t) for t in range(T)])
+    _, _, fuses = G.chain(key, labels, dains, want_all=False)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _, _, ofuses = generator_ref.autoregressive_segment(oracle(spec, sd), key, list(labels), list(dains))
+    d = [float((fuses[t].cpu() - ofuses[t]).abs().max()) for t in range(T)]
+    rep = {"workload": "512x512, 32-frame chain, batch 1", "fp32": {"max_abs_last_frame": d[-1], "max_abs_any_frame": max(d), "tolerance": NORTH_STAR_TOL}}
+    Gb = rib.Generator(rib.hsm_gen_config(), compute_dtype="bf16").eval()
+    Gb.load_state_dict(sd)
+    _, _, fb = Gb.chain(key, labels, dains, want_all=False)
+    db = [float((fb[t].cpu() - ofuses[t]).abs().max()) for t in range(T)]
+    mb = [float((fb[t].cpu() - ofuses[t]).abs().mean()) for t in range(T)]
+    rep["bf16"] = {"max_abs_last_frame": db[-1], "max_abs_any_frame": max(db), "mean_abs_last_frame": mb[-1], "mean_abs_worst_frame": max(mb),
+                   "bound_max_abs": 2.5e-1, "bound_mean_abs": 2e-2}
+    with open("gpurun_out/parity_config3_chain32_512.json", "w") as f:
+        json.dump(rep, f, indent=1)
+    assert max(d) <= NORTH_STAR_TOL, rep["fp32"]
+    assert max(db) <= 2.5e-1 and max(mb) <= 2e-2, rep["bf16"]
+    del Gb
+
+
+def test_config5_1024_batch4_matches_the_batch1_run():
+    """BASELINE configs[4]: 1024x1024, batch 4.  The B=4 plan (its own tuned tile choices, 4x workspace, blockIdx.z
+    ranges) against the B=1 plan sample by sample - which test_full_1024_against_oracle pins to the oracle at every
+    pixel - to fp32 summation-order tolerance; plus batch independence and determinism at this size."""
+    spec, sd, G = build("full", 0)
+    label, fake, prev = synth.make_inputs(spec, 4, 1024, 1024, 77)        # sample 0 == the oracle test's inputs
+    i4, m4 = [t.clone() for t in G(label, None, fake, prev)]
+    j4, n4 = G(label, None, fake, prev)
+    assert torch.equal(i4, j4) and torch.equal(m4, n4)
+    rep = {}
+    for b in (0, 3):
+        i1, m1 = G(label[b:b + 1], None, fake[b:b + 1], prev[b:b + 1])
+        rep[b] = (float((i1 - i4[b:b + 1]).abs().max()), float((m1 - m4[b:b + 1]).abs().max()))
+    with open("gpurun_out/parity_config5_1024_b4.json", "w") as f:
+        json.dump({"max_abs_vs_batch1 (img, mask)": rep, "tolerance": 5e-5}, f)
+    assert all(v[0] <= 5e-5 and v[1] <= 5e-5 for v in rep.values()), rep
+    assert float(i4.abs().max()) <= 1.0 and 0.0 <= float(m4.min()) and float(m4.max()) <= 1.0
+    G._ws.clear()
+    torch.cuda.empty_cache()
+
+
+def test_driver_lanes_follow_a_weight_reload(tmp_path):
+    """Evaluator keeps clones of the generator for its lanes; after load_state_dict on the model the clones must get
+    the new weights too (they used to keep the old blob: segments alternated between old and new weights)."""
+    from PIL import Image
+    from render_in_between_amd import evaluator as ev
+    from tests.test_driver import _write_example
+    root = str(tmp_path)
+    n = _write_example(root, n_key=4, rate=2, H=32, W=48)        # 3 independent segments -> 3 lanes
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=32, model_width=48, gauss_sigma=5,
+                       skeleton_thres=0.001, foot_thres=0.001)
+    spec = rib.GenSpec.from_cfg(cfg.gen)
+    dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
+    G = rib.Generator(rib.hsm_gen_config()).eval()
+    G.load_state_dict(synth.make_state_dict(spec, 0))
+    E = ev.Evaluator(cfg, lanes=3)
+    a = E.evaluate_from_folder(G, *dirs, os.path.join(root, "a"))
+    v0 = G.weights_version
+    G.load_state_dict(synth.make_state_dict(spec, 5))             # new checkpoint into the same object
+    assert G.weights_version == v0 + 1
+    b = E.evaluate_from_folder(G, *dirs, os.path.join(root, "b"))
+    G2 = rib.Generator(rib.hsm_gen_config()).eval()
+    G2.load_state_dict(synth.make_state_dict(spec, 5))
+    c = ev.Evaluator(cfg, lanes=1).evaluate_from_folder(G2, *dirs, os.path.join(root, "c"))
+    assert len(a) == len(b) == len(c) == n
+    differs = 0
+    for fa, fb, fc in zip(a, b, c):
+        xb = np.asarray(Image.open(fb))
+        assert np.array_equal(xb, np.asarray(Image.open(fc))), fb      # every segment rendered with the NEW weights
+        differs += not np.array_equal(xb, np.asarray(Image.open(fa)))
+    assert differs >= 3                                                # and the new weights do change the generated frames

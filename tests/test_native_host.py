@@ -113,6 +113,36 @@ def test_fold_and_layout_match_oracle(lib, cfgname):
     lib.rib_destroy(h)
 
 
+def test_partial_reload_after_finalize_folds_old_and_new_tensors(lib):
+    """load_state_dict(subset, strict=False) after a full load: rib_finalize_weights must fold the new tensors together
+    with the ones it already holds (the host copies stay after a finalize), not read freed storage."""
+    cfg = rib.hsm_gen_config(**MID_CFG)
+    spec, h = host_handle(lib, cfg)
+    sd = synth.make_state_dict(spec, 21)
+
+    def put(k, v):
+        t = v.contiguous()
+        d = (C.c_int64 * t.dim())(*t.shape)
+        assert lib.rib_set_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), d) == 0, lib.rib_last_error(h)
+
+    for k, v in sd.items():
+        put(k, v)
+    assert lib.rib_finalize_weights(h) == 0, lib.rib_last_error(h)
+    # second, partial load: one spectral-norm conv gets a new weight_orig (u, v, bias and every other layer stay)
+    name = "down_1.conv_block_0"
+    sd2 = dict(sd)
+    sd2[name + ".layers.conv.weight_orig"] = sd[name + ".layers.conv.weight_orig"] * 1.5 + 0.01
+    put(name + ".layers.conv.weight_orig", sd2[name + ".layers.conv.weight_orig"])
+    assert lib.rib_finalize_weights(h) == 0, lib.rib_last_error(h)
+    for cname, ref_sd in ((name, sd2), ("down_1.conv_block_1", sd), ("conv_img", sd)):
+        w_ref, b_ref = generator_ref.conv_weight(ref_sd, cname)
+        w = np.empty(tuple(w_ref.shape), np.float32); b = np.empty(w_ref.shape[0], np.float32)
+        assert lib.rib_debug_conv_weight(h, cname.encode(), w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+        assert np.abs(w - w_ref.numpy()).max() <= 2e-6 * float(w_ref.abs().max()), cname
+        assert np.array_equal(b, b_ref.numpy()), cname
+    lib.rib_destroy(h)
+
+
 def test_plan_flops_and_shape_rules(lib):
     spec, h = host_handle(lib, rib.hsm_gen_config())
     fl = (C.c_double * 6)()

@@ -149,3 +149,19 @@ def test_oracle_rasteriser_matches_reference_outputs(golden_dir):
         conf = list(kp[:, 2])
         assert np.array_equal(R.skeleton_image(lm, conf, H, W), g["skeleton"]), n
         assert np.array_equal(R.pose_map(lm, conf, H, W), g["pose_map"]), n
+
+
+def test_quantiser_restatement_equals_the_reference_bytes(golden_dir):
+    """The one byte-exact op on the path: oracle quantise_uint8 == the reference's tensor2images output
+    (tests/golden/quant_ref.npz, made by make_golden_quant.py from PGNR/utils/utils.py:122-147) bit for bit, on the
+    reference's own chain frame and on knife-edge values."""
+    import numpy as np
+    import torch
+    from oracle import generator_ref
+    g = np.load(os.path.join(golden_dir, "quant_ref.npz"))
+    c = np.load(os.path.join(golden_dir, "chain3_128.npz"))
+    assert np.array_equal(generator_ref.quantise_uint8(torch.from_numpy(c["fuse_last"])), g["chain_last_quant"])
+    assert np.array_equal(c["quant_last"], g["chain_last_quant"])
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(generator_ref.quantise_uint8(torch.from_numpy(g["edge_in"])), g["edge_quant"])
+    assert len(np.unique(g["edge_quant"])) == 256
