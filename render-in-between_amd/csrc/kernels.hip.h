@@ -104,7 +104,45 @@ struct IgemmParams {
   int nsets;             // 1 or 2 modulations of the same xm (conv_block_0 + conv_block_s)
   float* ys0; float* ys1;  // outputs [B][Hout][Wout][C]
   int act0, act1;
+  // --- consumer-side InstanceNorm finalize ---
+  // When the producer of a normalised tensor left few per-tile partial sums (<= STATS_MAX_PARTIALS), the consumer
+  // reduces them itself instead of reading (scale, shift) arrays written by a k_stats_finalize launch: one dependent
+  // launch (~5 us on a 3 ms frame, 44 of them) less per normalised tensor.  part = [B][tiles][2][Cs] fp32.
+  const float* pro_part; int pro_tiles, pro_Cs; float pro_inv;   // prologue: replaces pro_scale / pro_shift
+  const float* pro_gamma; const float* pro_beta;                 //   IN affine of the producer (mask network), or nullptr
+  const float* m_part; int m_tiles, m_Cs; float m_inv;           // SPADE epilogue: replaces m_scale / m_shift (no affine)
 };
+
+enum { STATS_MAX_PARTIALS = 128, STATS_MAX_PRO_CH = 512 };
+
+// (scale, shift) of ONE channel from the per-tile partial sums of its producer; `base` points at the sample's
+// [tiles][2][Cs] block.  Same arithmetic as k_stats_finalize (fp64 sums of the fp32 partials in tile order,
+// biased variance, eps 1e-5), so the two paths agree to the last bit whenever the tile order of the sum is the same.
+__device__ __forceinline__ void stats_from_partials(const float* base, int tiles, int Cs, int c, int t0, int tstep,
+                                                    double& a1, double& a2) {
+  a1 = 0.0; a2 = 0.0;
+  int t = t0;
+  for (; t + 3 * tstep < tiles; t += 4 * tstep) {   // 8 independent loads in flight
+    const float x0 = base[(size_t)t * 2 * Cs + c], y0 = base[(size_t)t * 2 * Cs + Cs + c];
+    const float x1 = base[(size_t)(t + tstep) * 2 * Cs + c], y1 = base[(size_t)(t + tstep) * 2 * Cs + Cs + c];
+    const float x2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + c], y2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + Cs + c];
+    const float x3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + c], y3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + Cs + c];
+    a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+    a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+  }
+  for (; t < tiles; t += tstep) {
+    a1 += (double)base[(size_t)t * 2 * Cs + c];
+    a2 += (double)base[(size_t)t * 2 * Cs + Cs + c];
+  }
+}
+__device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_count, float g, float b, float& sc, float& sh) {
+  const double mean = s1 * (double)inv_count;
+  double var = s2 * (double)inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+  sc = rstd * g;
+  sh = b - (float)mean * sc;
+}
 
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
@@ -179,6 +217,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   constexpr int PH = G::PH;
   static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+  // consumer-side InstanceNorm finalize: (scale, shift) of the input channels (prologue) / of this workgroup's
+  // modulated channels (SPADE epilogue), reduced from the producer's partial sums at kernel start
+  __shared__ __attribute__((aligned(16))) float s_stat[(PRO && !SPADE) ? 2 * STATS_MAX_PRO_CH : (SPADE ? 2 * (G::BN / 2) : 4)];
   float* sA = smem;
   float* sB = smem + G::NA * G::SA;
 
@@ -301,6 +342,15 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     iy = iy0 + ly; ix = ix0 + lx;
     return idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
   };
+  // prologue constants of chunk kc when they come from the consumer-side finalize (LDS, filled at kernel start)
+  auto pro_from_lds = [&](int kc) {
+    if constexpr (PRO && !SPADE) {
+      if (p.pro_part) {
+        psc = *reinterpret_cast<const float4*>(s_stat + kc + ac4 * 4);
+        psh = *reinterpret_cast<const float4*>(s_stat + STATS_MAX_PRO_CH + kc + ac4 * 4);
+      }
+    }
+  };
   auto prefetchA = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
@@ -316,6 +366,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         psh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * 4);
       }
     }
+    pro_from_lds(kc);
   };
   // fused prologue on the way into LDS: InstanceNorm affine + LeakyReLU; conv zero padding is
   // applied AFTER the transform (the reference pads the activated tensor)
@@ -326,13 +377,56 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       const bool inb = slot_inb(i, pix, iy, ix);
       float4 v = areg[i];
       if constexpr (PRO) {
-        if (!raw && p.pro_scale) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
+        if (!raw && (p.pro_scale || p.pro_part)) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
         if (!raw && p.pro_lrelu) v = lrelu4(v);
       }
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       int lpix = pix;
       if constexpr (STRIDE == 2) { const int ly = pix / G::IW, lx = pix % G::IW; lpix = ly * G::IWP + (lx & 1) * G::IWH + (lx >> 1); }
       if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + lpix * G::CK + ac4 * 4) = v;
+    }
+  };
+
+  // ---- consumer-side InstanceNorm finalize (see IgemmParams): called once, right after the first operand loads
+  // have been issued, so that the partial-sum loads overlap them ----
+  auto consumer_stats = [&]() {
+    if constexpr (PRO && !SPADE) {
+      if (p.pro_part) {
+        const float* base = p.pro_part + (size_t)n * p.pro_tiles * 2 * p.pro_Cs;
+        for (int c = tid; c < p.Cin; c += NT) {     // input channel c of x is channel c of its producer
+          double a1, a2;
+          stats_from_partials(base, p.pro_tiles, p.pro_Cs, c, 0, 1, a1, a2);
+          float sc, sh;
+          scale_shift_of(a1, a2, p.pro_inv, p.pro_gamma ? p.pro_gamma[c] : 1.f, p.pro_beta ? p.pro_beta[c] : 0.f, sc, sh);
+          s_stat[c] = sc; s_stat[STATS_MAX_PRO_CH + c] = sh;
+        }
+        __syncthreads();
+        pro_from_lds(kc_begin);
+      }
+    }
+    if constexpr (SPADE) {
+      if (p.m_part) {
+        // this workgroup modulates the virtual channels n0/2 .. n0/2 + BN/2 - 1; thread = (channel j, tile slice)
+        constexpr int NCH = G::BN / 2, S = NT / NCH;
+        const int j = tid % NCH, sl = tid / NCH;
+        const int v = n0 / 2 + j;
+        const bool vv = v < p.nsets * p.C;
+        const int c = vv ? (v >= p.C ? v - p.C : v) : 0;
+        double a1, a2;
+        stats_from_partials(p.m_part + (size_t)n * p.m_tiles * 2 * p.m_Cs, p.m_tiles, p.m_Cs, c, sl, S, a1, a2);
+        double* red = reinterpret_cast<double*>(smem);     // [S][NCH][2]; the main loop has not touched smem yet
+        red[(sl * NCH + j) * 2] = a1; red[(sl * NCH + j) * 2 + 1] = a2;
+        __syncthreads();
+        if (sl == 0) {
+          double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < S; ++k) { t1 += red[(k * NCH + j) * 2]; t2 += red[(k * NCH + j) * 2 + 1]; }
+          float sc, sh;
+          scale_shift_of(t1, t2, p.m_inv, 1.f, 0.f, sc, sh);
+          s_stat[j] = sc; s_stat[NCH + j] = sh;
+        }
+        __syncthreads();
+      }
     }
   };
 
@@ -435,6 +529,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     // the four taps of a phase per barrier (4 barriers per chunk instead of 16)
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
+    consumer_stats();
     int stage = 0;
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
       __syncthreads();
@@ -455,6 +550,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     // 16 (phase, tap) steps per chunk, fully unrolled so that the accumulator set is a compile-time choice
     loadB(kc_begin, 0);
     prefetchA(kc_begin);
+    consumer_stats();
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
       __syncthreads();
       writeA(false);
@@ -496,6 +592,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     // global loads were in flight during them); whoever is past the barrier of chunk k has finished chunk k-1
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
+    consumer_stats();
     writeA(false);
     storeB3(0);
     int stage = 0;
@@ -513,6 +610,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
+    consumer_stats();
     int stage = 0;
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
       __syncthreads();
@@ -536,6 +634,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   } else {
   loadB(kc_begin, 0);
   prefetchA(kc_begin);
+  consumer_stats();
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
     __syncthreads();   // every wave is done reading sA / sB of the previous chunk
     if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
@@ -810,7 +909,8 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       float bg = 0.f, bb = 0.f, sc = 0.f, sh = 0.f;
       if (vvalid) {
         bg = p.bias[colg]; bb = p.bias[colg + 32];
-        sc = p.m_scale[(size_t)n * p.m_ld + c]; sh = p.m_shift[(size_t)n * p.m_ld + c];
+        if (p.m_part) { sc = s_stat[v - n0 / 2]; sh = s_stat[G::BN / 2 + v - n0 / 2]; }   // consumer-side finalize
+        else { sc = p.m_scale[(size_t)n * p.m_ld + c]; sh = p.m_shift[(size_t)n * p.m_ld + c]; }
       }
       float* yout = set ? p.ys1 : p.ys0;
       const int act = set ? p.act1 : p.act0;

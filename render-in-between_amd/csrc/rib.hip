@@ -242,7 +242,7 @@ struct Variant {
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
   if (p.x2 != nullptr) return v->fn;
-  if (p.pro_scale == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
+  if (p.pro_scale == nullptr && p.pro_part == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
   return v->fn_pro ? v->fn_pro : v->fn;
 }
 
@@ -343,10 +343,12 @@ struct Op {
   int record_ev = -1;         // plan event recorded on its stream after it launches
   // igemm
   const Variant* var = nullptr;
+  std::string for_op;        // a finalize launch emitted on behalf of this consumer (rib_time_op times them together)
   bool label_only = false;   // depends on the label map only (pack.label, down_first, the mask network's label branch)
   int small_co = 0;   // > 0: direct vector-ALU convolution k_conv_small<small_co> instead of the matrix-core kernel
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
+  PRef pro_part, pro_gamma, pro_beta, m_part;   // consumer-side InstanceNorm finalize (IgemmParams)
   // split-K epilogue
   SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
   // unfused SPADE modulate
@@ -363,15 +365,27 @@ struct Op {
   PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
 };
 
+struct PendingStats {
+  Op fin;
+  bool pushed = false;
+  size_t part_off = 0; int tiles = 0, Cs = 0; float inv_count = 0.f;
+  bool affine = false; size_t g_off = 0, be_off = 0;
+};
+
 struct Tap { std::string name; size_t off; int Cp, C, H, W; };
 
 struct Act {       // NHWC activation in the workspace
   size_t off = 0;  // bytes
   int Cp = 0, C = 0, H = 0, W = 0;
 };
+struct PendingStats;
 struct Norm {      // (scale, shift) arrays [B][ld]
   size_t sc = 0, sh = 0; int ld = 0;
   bool valid = false;
+  // the k_stats_finalize launch that would fill the arrays, not emitted yet: a consumer that can reduce the
+  // producer's partial sums itself (k_igemm prologue / SPADE epilogue, few partials) takes them from here and the
+  // launch never happens; any other consumer emits it first (Builder::materialize)
+  std::shared_ptr<PendingStats> pend;
 };
 
 // results of the label-only launches, as (offset, bytes) into the plan's workspace: in an autoregressive chain the
@@ -534,6 +548,22 @@ struct Builder {
 
   int new_event() { return P->num_events++; }
   bool mark_label = false;
+  bool defer_stats = true;   // false: every k_stats_finalize launch is emitted where its producer is (labels-only plans)
+  // a consumer needs the (scale, shift) ARRAYS of n: emit the finalize launch now if it is still pending
+  void materialize(const Norm& n, const std::string& consumer = std::string()) {
+    if (n.pend && !n.pend->pushed) { n.pend->pushed = true; n.pend->fin.for_op = consumer; push(n.pend->fin); }
+  }
+  // the producer's partial sums are still there for a consumer-side finalize
+  static bool has_partials(const Norm& n) { return n.pend && !n.pend->pushed; }
+  // emit or defer the finalize launch f of a producer with `tiles` partials per sample
+  void finalize_or_defer(Op& f, Norm* out, bool now, size_t part_off, int tiles, int Cs, float inv_count, bool affine, size_t g_off, size_t be_off) {
+    static const bool off = getenv("RIB_NO_CONSUMER_STATS") != nullptr;
+    if (now || off || !defer_stats || mark_label || tiles > STATS_MAX_PARTIALS) { push(f); return; }
+    auto ps = std::make_shared<PendingStats>();
+    ps->fin = f; ps->part_off = part_off; ps->tiles = tiles; ps->Cs = Cs; ps->inv_count = inv_count;
+    ps->affine = affine; ps->g_off = g_off; ps->be_off = be_off;
+    out->pend = ps;
+  }
   int tuneB = 0;      // batch whose tuned choices / cost-model decisions this plan follows (0: its own).  The labels-only
                       // plan of a chain follows the frame plan's, so that its results are bit-identical to per-frame launches
   int TB_() const { return tuneB > 0 ? tuneB : B; }
@@ -582,6 +612,7 @@ struct Builder {
     bool want_stats = false;
     Norm* stats_out = nullptr; size_t stats_choff = 0;  // finalize target (+channel offset)
     bool affine = false;    // finalize with the conv's IN gamma/beta
+    bool stats_now = false; // emit the finalize launch at the producer (the arrays are shared / copied between plans)
   };
 
   bool conv(const ConvArgs& a, const std::string& opname) {
@@ -623,7 +654,22 @@ struct Builder {
     if (a.ups && (!c.ups_in || c.ks != 3 || c.stride != 1)) { error = opname + ": no phase filters for this upsample convolution"; return false; }
     p.act = a.act; p.ksplit = S;
     op.x = WS(a.in.off);
-    if (a.pro) { op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float)); }
+    // heads with 1..4 output channels (conv_img, conv_mask.0): direct convolution on the vector ALUs; the
+    // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
+    const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
+                       c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
+                       !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
+    if (a.pro) {
+      // consumer-side finalize: this launch reduces the producer's partial sums in its prologue
+      if (has_partials(*a.pro) && a.pro_choff == 0 && !small && c.cinp <= STATS_MAX_PRO_CH && c.cinp <= a.pro->pend->Cs) {
+        const PendingStats& ps = *a.pro->pend;
+        op.pro_part = WS(ps.part_off); p.pro_tiles = ps.tiles; p.pro_Cs = ps.Cs; p.pro_inv = ps.inv_count;
+        if (ps.affine) { op.pro_gamma = WT(ps.g_off); op.pro_beta = WT(ps.be_off); }
+      } else {
+        materialize(*a.pro, opname);
+        op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float));
+      }
+    }
     op.w = WT(a.ups ? c.wp_off : c.w_off); op.bias = WT(c.b_off);
     double aux_flops = 0.0;
     if (a.aux) {
@@ -642,11 +688,6 @@ struct Builder {
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
-    // heads with 1..4 output channels (conv_img, conv_mask.0): direct convolution on the vector ALUs; the
-    // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
-    const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
-                       c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
-                       !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
     if (small) {
       op.small_co = c.cout;
       p.ksplit = 1;
@@ -694,7 +735,9 @@ struct Builder {
       if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
       f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
       f.grid = dim3(c.coutp / 16, B, 1);
-      push(f);
+      // (a channel offset means two producers share the arrays - the concatenated encoders of the mask network -
+      // and consumers would need two partial sources: those keep their launch)
+      finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
     }
     return true;
   }
@@ -729,6 +772,7 @@ struct Builder {
     }
     if (!unfused && !v) { error = "no SPADE variant"; return false; }
     if (unfused) {
+      materialize(nx, key + ".spade");
       *ys0 = act(sg.C, Hout, Wout);
       if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
       const Variant* cv = uf.v; const int S = uf.ksplit;
@@ -768,7 +812,14 @@ struct Builder {
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
     op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off);
-    op.xm = WS(x.off); op.m_scale = WS(nx.sc); op.m_shift = WS(nx.sh);
+    op.xm = WS(x.off);
+    if (has_partials(nx) && !nx.pend->affine && sg.Cp <= nx.pend->Cs) {   // consumer-side finalize in the SPADE epilogue
+      const PendingStats& ps = *nx.pend;
+      op.m_part = WS(ps.part_off); p.m_tiles = ps.tiles; p.m_Cs = ps.Cs; p.m_inv = ps.inv_count;
+    } else {
+      materialize(nx, key + ".spade");
+      op.m_scale = WS(nx.sc); op.m_shift = WS(nx.sh);
+    }
     op.ys0 = WS(ys0->off); if (sg.nsets == 2) op.ys1 = WS(ys1->off);
     op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + v->BN() - 1) / v->BN(), B);
     op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
@@ -854,6 +905,7 @@ struct Builder {
     const rib_config& c = g.c;
     const int H = P->H, W = P->W;
     P->labels_only = true;
+    defer_stats = false;
     Act L = act(c.label_nc, H, W);
     if (L.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }
     {
@@ -991,7 +1043,7 @@ struct Builder {
         f.fp.inv_count = 1.0f / ((float)pooled.H * (float)pooled.W); f.fp.eps = 1e-5f;
         f.f_part = WS(part); f.f_scale = WS(np.sc); f.f_shift = WS(np.sh);
         f.grid = dim3((out.Cp + 15) / 16, B, 1);
-        push(f);
+        finalize_or_defer(f, &np, false, part, blocks, out.Cp, f.fp.inv_count, false, 0, 0);
         x = pooled; nx = np;
       } else { x = out; nx = nout; }
     }
@@ -1044,6 +1096,8 @@ struct Builder {
         if (!conv(a, cs.name)) return false;
       } else if (first) { error = "mask res block 0 must have a learned shortcut"; return false; }
       Act o = act(c1.cout, Hm, Wm);
+      materialize(n1);
+      if (learned) materialize(ns);
       Op op; op.kind = OP_INADD; op.kclass = RIB_KC_ELTWISE; op.name = bn + ".join";
       memset(&op.ap, 0, sizeof op.ap);
       op.ap.C = o.Cp; op.ap.HW = Hm * Wm; op.ap.ld = n1.ld;
@@ -1150,6 +1204,8 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
+        p.pro_part = R.get<const float>(op.pro_part); p.pro_gamma = R.get<const float>(op.pro_gamma); p.pro_beta = R.get<const float>(op.pro_beta);
+        p.m_part = R.get<const float>(op.m_part);
         if (op.small_co > 0) {
           const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
           switch (op.small_co) {
@@ -1780,7 +1836,7 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   Plan sub; sub.B = B; sub.H = H; sub.W = W;
   const std::string nm = op_name;
   for (const Op& op : P->ops)
-    if (op.name == nm || op.name == nm + ".splitk_sum" || op.name == nm + ".modulate") sub.ops.push_back(op);
+    if (op.name == nm || op.name == nm + ".splitk_sum" || op.name == nm + ".modulate" || op.for_op == nm) sub.ops.push_back(op);
   if (sub.ops.empty()) return fail(h, RIB_ERR_INVALID, fmt("rib_time_op: no op named '%s'", op_name));
   Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;

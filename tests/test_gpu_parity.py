@@ -431,7 +431,8 @@ def test_direct_head_convolutions_agree_with_the_matrix_core_path(monkeypatch):
         G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
         i2, m2 = G2(label, None, fake, prev)
         torch.cuda.synchronize()
-        assert n1 == G2._lib.rib_num_launches(G2._h, 1, H, W)
+        # (through k_igemm, conv_mask.0 may also finalise up_flow.5's statistics itself: one launch less)
+        assert n1 - G2._lib.rib_num_launches(G2._h, 1, H, W) in (0, 1)
         e = max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max()))
         assert e < 2e-6, (H, W, e)
         del G1, G2
