@@ -159,7 +159,11 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
              float* out, void* hip_stream);
 
 /* ---- introspection for parity tests (no reference counterpart) ----
- * After a rib_forward on `workspace`, intermediate activations can be read back as NCHW. */
+ * After a rib_forward on `workspace`, intermediate activations can be read back as NCHW - the reference-side
+ * equivalent is a forward hook on a leaf module.  The plan gives buffers with disjoint lifetimes
+ * the same workspace bytes, so taps must be switched on BEFORE the forward: rib_set_debug_taps(h, 1) keeps every
+ * tapped activation intact until the end of the forward (and rebuilds the launch plans). */
+int rib_set_debug_taps(rib_handle* h, int enable);
 int rib_num_taps(rib_handle* h, int B, int H, int W);
 int rib_tap_info(rib_handle* h, int B, int H, int W, int idx, const char** name, int* C, int* th,
                  int* tw);

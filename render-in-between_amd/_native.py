@@ -56,6 +56,7 @@ SIGNATURES = {
     "rib_rasterise": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                 C.c_void_p]),
+    "rib_set_debug_taps": (C.c_int, [C.c_void_p, C.c_int]),
     "rib_num_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rib_tap_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

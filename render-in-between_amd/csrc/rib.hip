@@ -14,6 +14,7 @@
 #include "../../include/rib.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -399,6 +400,7 @@ struct Plan {
   int B, H, W;
   int num_events = 0;
   size_t ws_bytes = 0;
+  size_t ws_virtual = 0;   // bytes before lifetime-based reuse (one range per buffer)
   std::vector<Op> ops;
   std::vector<Tap> taps;
   double flops[RIB_KC_COUNT] = {0};
@@ -421,6 +423,7 @@ struct rib_handle {
   size_t blob_floats = 0;
   bool weights_ready = false;
   bool compute_bf16 = false;   // rib_set_compute_dtype
+  bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
@@ -578,7 +581,17 @@ struct Builder {
   int record_after_last() { const int e = new_event(); P->ops.back().record_ev = e; return e; }
   void wait_before_next(int ev) { if (ev >= 0) pending_waits.push_back(ev); }
 
-  size_t alloc(size_t bytes) { size_t o = ws; ws += align256(bytes); return o; }
+  // Workspace layout.  During the build every buffer gets its own range of a virtual address space (bump
+  // allocation, as the plan used to run: 1.1 GB at 512x512); assign_physical() then gives buffers whose lifetimes
+  // (first .. last launch that touches them) do not overlap the same bytes, so that the working set of a frame stays
+  // inside the 256 MB memory-side cache instead of streaming 1.1 GB of distinct addresses through it.
+  struct AllocRec { size_t voff, bytes, phys; int first, last; };
+  std::vector<AllocRec> allocs;
+  size_t alloc(size_t bytes) {
+    size_t o = ws; ws += align256(bytes);
+    allocs.push_back(AllocRec{o, align256(bytes), o, INT_MAX, -1});
+    return o;
+  }
   Act act(int C, int H, int W) {
     Act a; a.C = C; a.Cp = pad8(C); a.H = H; a.W = W;
     a.off = alloc((size_t)B * H * W * a.Cp * sizeof(float));
@@ -890,6 +903,71 @@ struct Builder {
     return true;
   }
 
+  template <typename F> static void for_each_pref(Op& op, F f) {
+    PRef* all[] = {&op.x, &op.pro_scale, &op.pro_shift, &op.w, &op.bias, &op.y, &op.res, &op.y_nchw, &op.stat, &op.xm, &op.m_scale,
+                   &op.m_shift, &op.ys0, &op.ys1, &op.slab, &op.x2, &op.w2, &op.pro_part, &op.pro_gamma, &op.pro_beta, &op.m_part,
+                   &op.s_slab, &op.s_bias, &op.s_y, &op.s_res, &op.s_stat, &op.m_slab, &op.m_bias, &op.m_xm, &op.m_sc, &op.m_sh,
+                   &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
+                   &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst};
+    for (PRef* r : all) if (r->sp == PS_WS) f(*r);
+  }
+  AllocRec* alloc_of(size_t voff) {
+    // allocations are in increasing voff order
+    size_t lo = 0, hi = allocs.size();
+    while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if (allocs[mid].voff <= voff) lo = mid; else hi = mid; }
+    return (!allocs.empty() && voff >= allocs[lo].voff && voff < allocs[lo].voff + allocs[lo].bytes) ? &allocs[lo] : nullptr;
+  }
+  // Lifetime analysis + placement; rewrites every workspace reference of the plan.  The plan runs its launches in
+  // order on one stream, so a buffer is live from the first to the last launch that names it; buffers written outside
+  // the plan (the label-only results rib_chain gathers into their slots before it runs the frame) are live from the
+  // start, tapped activations (debug) until the end.
+  bool assign_physical() {
+    const bool reuse = !getenv("RIB_NO_WS_REUSE") && !h->use_streams && !P->labels_only;
+    if (!reuse) { P->ws_bytes = ws; return true; }
+    bool bad = false;
+    for (size_t i = 0; i < P->ops.size(); ++i)
+      for_each_pref(P->ops[i], [&](PRef& r) {
+        AllocRec* a = alloc_of(r.off);
+        if (!a) { bad = true; return; }
+        a->first = std::min(a->first, (int)i); a->last = std::max(a->last, (int)i);
+      });
+    if (bad) { error = "workspace reference outside every allocation"; return false; }
+    const LabelSlots& l = P->ls;
+    for (size_t off : {l.x0, l.nx_sc, l.nx_sh, l.cat, l.ncat_sc, l.ncat_sh})
+      if (AllocRec* a = alloc_of(off)) a->first = -1;
+    if (h->keep_taps)
+      for (const Tap& t : P->taps)
+        if (AllocRec* a = alloc_of(t.off)) a->last = INT_MAX;
+    // placement: largest first, each at the lowest offset where it does not meet a placed buffer with an overlapping lifetime
+    std::vector<int> order;
+    for (size_t i = 0; i < allocs.size(); ++i) if (allocs[i].last >= 0 || allocs[i].first == -1) order.push_back((int)i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return allocs[a].bytes != allocs[b].bytes ? allocs[a].bytes > allocs[b].bytes : a < b; });
+    std::vector<int> placed;
+    size_t top = 0;
+    for (int i : order) {
+      AllocRec& a = allocs[i];
+      std::vector<std::pair<size_t, size_t>> busy;     // physical ranges of the placed buffers alive together with a
+      for (int j : placed) {
+        const AllocRec& b = allocs[j];
+        if (b.first <= a.last && a.first <= b.last) busy.push_back({b.phys, b.phys + b.bytes});
+      }
+      std::sort(busy.begin(), busy.end());
+      size_t at = 0;
+      for (auto& r : busy) { if (at + a.bytes <= r.first) break; at = std::max(at, r.second); }
+      a.phys = at;
+      top = std::max(top, at + a.bytes);
+      placed.push_back(i);
+    }
+    auto remap = [&](size_t voff) { AllocRec* a = alloc_of(voff); return a ? a->phys + (voff - a->voff) : voff; };
+    for (Op& op : P->ops) for_each_pref(op, [&](PRef& r) { r.off = remap(r.off); });
+    LabelSlots& m = P->ls;
+    m.x0 = remap(m.x0); m.nx_sc = remap(m.nx_sc); m.nx_sh = remap(m.nx_sh); m.cat = remap(m.cat); m.ncat_sc = remap(m.ncat_sc); m.ncat_sh = remap(m.ncat_sh);
+    for (Tap& t : P->taps) t.off = remap(t.off);
+    P->ws_virtual = ws;
+    P->ws_bytes = top;
+    return true;
+  }
+
   void record_label_slots(const Act& x, const Norm& nx, const Act& CAT, const Norm& ncat) {
     LabelSlots& l = P->ls;
     l.x0 = x.off; l.x0_b = (size_t)B * x.H * x.W * x.Cp * sizeof(float);
@@ -926,8 +1004,7 @@ struct Builder {
     ConvArgs a; a.cd = &df; a.in = L; a.out = x; a.want_stats = true; a.stats_out = &nx;
     if (!conv(a, "down_first")) return false;
     record_label_slots(x, nx, CAT, ncat);
-    P->ws_bytes = ws;
-    return true;
+    return assign_physical();
   }
 
   bool build() {
@@ -1128,9 +1205,7 @@ struct Builder {
       a.act = ACT_SIGMOID; a.y_user = US(U_MASK);
       if (!conv(a, cm.name)) return false;
     }
-    // chain scratch: fused frame of the previous step (NCHW)
-    P->ws_bytes = ws;
-    return true;
+    return assign_physical();
   }
 };
 
@@ -1544,7 +1619,10 @@ int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, ui
 int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const float* flow, float* out, void* hip_stream) {
   if (!h || !img || !flow || !out) return RIB_ERR_INVALID;
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_warp, dim3((H * W + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W);
+  if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
+  const int tilesX = (W + WARP_T - 1) / WARP_T, tilesY = (H + WARP_T - 1) / WARP_T;
+  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);
+  hipLaunchKernelGGL(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -1701,6 +1779,13 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
   return RIB_OK;
 }
 
+int rib_set_debug_taps(rib_handle* h, int enable) {
+  if (!h) return RIB_ERR_INVALID;
+  if (h->keep_taps != (enable != 0)) h->plans.clear();   // the workspace layout depends on it
+  h->keep_taps = enable != 0;
+  return RIB_OK;
+}
+
 int rib_num_taps(rib_handle* h, int B, int H, int W) {
   if (!h) return RIB_ERR_INVALID;
   Plan* P = get_plan(h, B, H, W);
@@ -1721,6 +1806,7 @@ int rib_tap_info(rib_handle* h, int B, int H, int W, int idx, const char** name,
 
 int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* workspace, float* dst, void* hip_stream) {
   if (!h || !workspace || !dst) return RIB_ERR_INVALID;
+  if (!h->keep_taps) return fail(h, RIB_ERR_STATE, "rib_read_tap: call rib_set_debug_taps(h, 1) before the forward (intermediate buffers are reused otherwise)");
   Plan* P = get_plan(h, B, H, W);
   if (!P || idx < 0 || idx >= (int)P->taps.size()) return RIB_ERR_INVALID;
   const Tap& t = P->taps[idx];

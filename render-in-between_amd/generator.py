@@ -298,8 +298,15 @@ class Generator:
         return out
 
     # ---- introspection / measurement -----------------------------------------------------------
+    def enable_taps(self, on=True):
+        """Debug: keep every tapped intermediate intact until the end of a forward (buffers with disjoint lifetimes
+        share workspace bytes otherwise).  Rebuilds the launch plans; call before the forward whose taps are read."""
+        _native.check(self._h, self._lib.rib_set_debug_taps(self._h, 1 if on else 0))
+        self._ws.clear()
+        return self
+
     def read_taps(self, B, H, W):
-        """Intermediate activations of the LAST forward at this shape, as NCHW CPU tensors."""
+        """Intermediate activations of the LAST forward at this shape (run after enable_taps()), as NCHW CPU tensors."""
         ws = self._workspace(B, H, W)
         out = {}
         name = C.c_char_p(); ch = C.c_int(); th = C.c_int(); tw = C.c_int()

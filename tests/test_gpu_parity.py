@@ -62,9 +62,16 @@ def test_layer_taps_match_oracle_mid64():
     a wrong kernel variant to the first diverging layer."""
     spec, sd, G = build("mid", 7)
     label, fake, prev = synth.make_inputs(spec, 1, 64, 64, 7)
+    img0, mask0 = [t.clone() for t in G(label, None, fake, prev)]     # production plan: buffers reused
+    from render_in_between_amd import _native
+    with pytest.raises(_native.RibError, match="rib_set_debug_taps"):
+        G.read_taps(1, 64, 64)
+    G.enable_taps()
     img, mask = G(label, None, fake, prev)
     torch.cuda.synchronize()
+    assert torch.equal(img, img0) and torch.equal(mask, mask0)        # the workspace layout does not change a bit
     taps = G.read_taps(1, 64, 64)
+    G.enable_taps(False)
     otaps = {}
     oimg, omask = oracle(spec, sd)(label, None, fake, prev, taps=otaps)
     report = {}
@@ -187,6 +194,20 @@ def test_warp_extension_matches_grid_sample():
     ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
     out = G.warp(img, flow).cpu()
     assert float((out - ref).abs().max()) <= 2e-5
+    # k_warp stages a window of 8 pixels of flow reach around each 16x16 output tile in LDS; flows that reach further
+    # take the global-load path.  Sizes that do not tile evenly, flows far beyond the window and beyond the frame.
+    for (B, H, W, amp, seed) in ((1, 50, 70, 7.9, 1), (2, 50, 70, 120.0, 2), (1, 17, 33, 40.0, 3), (1, 128, 128, 16.0, 4)):
+        g = torch.Generator().manual_seed(seed)
+        img = synth.smooth_image(spec, B, H, W, 70 + seed)
+        flow = (torch.rand(B, 2, H, W, generator=g) - 0.5) * 2 * amp
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+        grid = torch.stack([xs, ys], -1)[None].repeat(B, 1, 1, 1)
+        grid = grid + torch.stack([flow[:, 0] * 2 / (W - 1), flow[:, 1] * 2 / (H - 1)], -1)
+        ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+        out = G.warp(img, flow).cpu()
+        assert float((out - ref).abs().max()) <= 5e-5, (B, H, W, amp)
+    # zero flow is the identity (up to the fp32 un-normalisation of the sampling grid)
+    assert float((G.warp(img, torch.zeros_like(flow)).cpu() - img).abs().max()) <= 1e-4
 
 
 def test_weight_export_import_roundtrip_is_bit_exact():
