@@ -42,6 +42,40 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float4 lo, const float4 hi) {
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
+// ---- storage type of the activations / filters: fp32 (default, the reference's arithmetic) or bf16 (BASELINE
+// configs[2]: bf16 NHWC tensors in HBM and bf16 tiles in LDS - half the bytes everywhere - bf16 matrix-core
+// operands, fp32 accumulation, fp32 InstanceNorm statistics of the ROUNDED values, fp32 SPADE arithmetic).
+// Pointers stay `float*` in the parameter structs; a BF16 kernel indexes them as 2-byte elements.
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float v) {      // round to nearest even (v_cvt_pk_bf16_f32)
+  const __bf16 b = (__bf16)v;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <bool BF16> __device__ __forceinline__ float ld_act(const float* base, size_t i) {
+  if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t*>(base)[i]);
+  else return base[i];
+}
+template <bool BF16> __device__ __forceinline__ void st_act(float* base, size_t i, float v) {
+  if constexpr (BF16) reinterpret_cast<uint16_t*>(base)[i] = f32_to_bf16(v);
+  else base[i] = v;
+}
+// four consecutive elements (16 B of fp32 / 8 B of bf16)
+template <bool BF16> __device__ __forceinline__ float4 ld_act4(const float* base, size_t i) {
+  if constexpr (BF16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + i);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  } else return *reinterpret_cast<const float4*>(base + i);
+}
+template <bool BF16> __device__ __forceinline__ void st_act4(float* base, size_t i, float4 v) {
+  if constexpr (BF16) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + i) = r;
+  } else *reinterpret_cast<float4*>(base + i) = v;
+}
+
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 __device__ __forceinline__ float4 lrelu4(float4 v) {
   return make_float4(lrelu(v.x), lrelu(v.y), lrelu(v.z), lrelu(v.w));
@@ -84,6 +118,7 @@ struct IgemmParams {
   // --- conv epilogue ---
   float* y;              // [B][Hout][Wout][yC], written at channel offset yoff
   int yC, yoff, Cout;    // Cout = valid output channels
+  int y_f32;             // bf16-storage kernels: y is a caller's fp32 tensor (the mask head), not a workspace activation
   int act;
   const float* res;      // residual added before act/store, [B][Hout][Wout][resC] or nullptr
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
@@ -147,7 +182,7 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
 // WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1>
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, bool BF16 = false>
 struct IgemmGeom {
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
@@ -159,7 +194,10 @@ struct IgemmGeom {
   static constexpr int PH = UPS ? 4 : 1;
   static constexpr int IH = UPS ? (TH + 2) : ((TH - 1) * STRIDE + KS);
   static constexpr int IW = UPS ? (TW + 2) : ((TW - 1) * STRIDE + KS);
-  static constexpr int CK = BK + 4;            // padded LDS row: conflict-free ds_read_b128
+  static constexpr int EPS = BF16 ? 8 : 4;     // elements per 16-byte staging slot
+  static constexpr int KF = BK * 4 / EPS;      // floats of LDS one pixel's / filter row's K chunk takes (bf16: BK / 2)
+  static constexpr int GPR = KF / 4;           // 16-byte slots per row
+  static constexpr int CK = KF + 4;            // padded LDS row: conflict-free ds_read_b128
   // Stride 2: the halo tile is stored with even and odd columns de-interleaved (column x -> (x & 1) * IWH + x / 2),
   // so that the 16 lanes of a ds_read_b128 phase, which step 2 pixels in x, read consecutive LDS pixels as in the
   // stride-1 case (stepping 2 * CK floats they hit only half of the banks: 35-49 % of the LDS cycles of the
@@ -172,7 +210,7 @@ struct IgemmGeom {
   static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
   static constexpr int SA = IH * IWP * CK;     // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
-  static constexpr int NB4 = (BN * BK / 4 + NT - 1) / NT; // float4 filter loads per thread per tap
+  static constexpr int NB4 = (BN * GPR + NT - 1) / NT;     // 16-byte filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   static constexpr int NA = TB == 9 ? 2 : 1;   // TB = 9 also double-buffers the input tile: one barrier per chunk
@@ -203,19 +241,21 @@ struct IgemmGeom {
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
-  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB> G;
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, BF16> G;
+  constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored element (activations and filters)
+  constexpr int EPS = G::EPS, GPR = G::GPR;
   static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS),
                 "filter slices per barrier: one tap, one row of a 3x3 filter, all nine; phase convolutions: the four taps of a phase");
   constexpr int NT = G::NT;
-  static_assert(KW == 1 || (!BF16 && NF > 0 && (BK / 8) % KW == 0), "in-workgroup split-K: fp32 32-column path (conv or SPADE), BK/8 divisible by KW");
+  static_assert(KW == 1 || (NF > 0 && (BK / (BF16 ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
-  static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0), "16-column path: 8x16-style tiles only");
+  static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0 && !BF16), "16-column path: 8x16-style tiles only, fp32");
   static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && (TB == 1 || TB == 4) && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
   constexpr int PH = G::PH;
-  static_assert(NT % (BK / 4) == 0, "a thread keeps one channel group across its staging slots");
+  static_assert(NT % GPR == 0, "a thread keeps one channel group across its staging slots");
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   // consumer-side InstanceNorm finalize: (scale, shift) of the input channels (prologue) / of this workgroup's
   // modulated channels (SPADE epilogue), reduced from the producer's partial sums at kernel start
@@ -277,8 +317,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         for (int r = 0; r < 4; ++r) acc16[mf][sub][r] = 0.f;
   }
 
-  const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
-  const int wrow = G::TAPS * p.Cin;   // floats per filter row
+  const char* xn = reinterpret_cast<const char*>(p.x) + (size_t)n * p.Hin * p.Win * p.xC * ESZ;
+  const char* wb = reinterpret_cast<const char*>(p.w);
+  const int wrow = G::TAPS * p.Cin;   // elements per filter row
 
   // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
   // filter slice / input chunk are in flight while the current one feeds the matrix cores ----
@@ -287,11 +328,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
       const int idx = tid + i * NT;
-      const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+      const int row = idx / GPR, c4 = idx % GPR;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < G::BN && n0 + row < p.CoutPad)
         v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
-                          : *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * 4);
+                          : *reinterpret_cast<const float4*>(wb + ((size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * EPS) * ESZ);
       breg[i] = v;
     }
   };
@@ -299,7 +340,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
       const int idx = tid + i * NT;
-      const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+      const int row = idx / GPR, c4 = idx % GPR;
       if (row < G::BN)
         *reinterpret_cast<float4*>(sB + buf * G::SB + row * G::CK + c4 * 4) = breg[i];
     }
@@ -311,10 +352,10 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        const int row = idx / GPR, c4 = idx % GPR;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(p.w + (size_t)(n0 + row) * wrow + (dy * (TB == 4 ? 4 : 3) + t) * p.Cin + kc + c4 * 4);
+          v = *reinterpret_cast<const float4*>(wb + ((size_t)(n0 + row) * wrow + (dy * (TB == 4 ? 4 : 3) + t) * p.Cin + kc + c4 * EPS) * ESZ);
         breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
@@ -324,20 +365,23 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        const int row = idx / GPR, c4 = idx % GPR;
         if (row < G::BN)
           *reinterpret_cast<float4*>(sB + (buf * (TB > 1 ? TB : 3) + t) * G::SB + row * G::CK + c4 * 4) = breg[(TB > 1 ? t : 0) * G::NB4 + i];
       }
   };
 
-  constexpr int total4 = G::IH * G::IW * (BK / 4);
+  constexpr int total4 = G::IH * G::IW * GPR;
   constexpr int NA4 = (total4 + NT - 1) / NT;
-  const int ac4 = tid % (BK / 4);           // this thread's channel group, the same in every slot
-  float4 areg[NA4];
-  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ac4 = tid % GPR;                // this thread's channel group (EPS channels), the same in every slot
+  float4 areg[NA4];                         // 16 raw bytes per slot: 4 fp32 or 8 bf16 channels
+  constexpr int PV = EPS / 4;               // float4s of prologue constants per slot
+  float4 psc[PV], psh[PV];
+#pragma unroll
+  for (int q = 0; q < PV; ++q) { psc[q] = make_float4(1.f, 1.f, 1.f, 1.f); psh[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
   auto slot_inb = [&](int i, int& pix, int& iy, int& ix) -> bool {
     const int idx = tid + i * NT;
-    pix = idx / (BK / 4);
+    pix = idx / GPR;
     const int ly = pix / G::IW, lx = pix % G::IW;
     iy = iy0 + ly; ix = ix0 + lx;
     return idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
@@ -346,8 +390,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   auto pro_from_lds = [&](int kc) {
     if constexpr (PRO && !SPADE) {
       if (p.pro_part) {
-        psc = *reinterpret_cast<const float4*>(s_stat + kc + ac4 * 4);
-        psh = *reinterpret_cast<const float4*>(s_stat + STATS_MAX_PRO_CH + kc + ac4 * 4);
+#pragma unroll
+        for (int q = 0; q < PV; ++q) {
+          psc[q] = *reinterpret_cast<const float4*>(s_stat + kc + ac4 * EPS + q * 4);
+          psh[q] = *reinterpret_cast<const float4*>(s_stat + STATS_MAX_PRO_CH + kc + ac4 * EPS + q * 4);
+        }
       }
     }
   };
@@ -357,13 +404,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       int pix, iy, ix;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (slot_inb(i, pix, iy, ix))
-        v = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + kc + ac4 * 4));   // < 2^31 elements per sample (checked by the host)
+        v = *reinterpret_cast<const float4*>(xn + (size_t)(unsigned)((iy * p.Win + ix) * p.xC + kc + ac4 * EPS) * ESZ);   // < 2^31 elements per sample (checked by the host)
       areg[i] = v;
     }
     if constexpr (PRO) {
       if (p.pro_scale) {
-        psc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + ac4 * 4);
-        psh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * 4);
+#pragma unroll
+        for (int q = 0; q < PV; ++q) {
+          psc[q] = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + kc + ac4 * EPS + q * 4);
+          psh[q] = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + kc + ac4 * EPS + q * 4);
+        }
       }
     }
     pro_from_lds(kc);
@@ -377,8 +427,32 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       const bool inb = slot_inb(i, pix, iy, ix);
       float4 v = areg[i];
       if constexpr (PRO) {
-        if (!raw && (p.pro_scale || p.pro_part)) v = make_float4(v.x * psc.x + psh.x, v.y * psc.y + psh.y, v.z * psc.z + psh.z, v.w * psc.w + psh.w);
-        if (!raw && p.pro_lrelu) v = lrelu4(v);
+        const bool aff = !raw && (p.pro_scale || p.pro_part), lr = !raw && p.pro_lrelu;
+        if constexpr (BF16) {
+          if (aff || lr) {        // 8 packed bf16 channels: unpack, fp32 prologue, round back
+            const uint32_t w[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e[2 * k] = __uint_as_float(w[k] << 16); e[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            if (aff) {
+              const float sc[8] = {psc[0].x, psc[0].y, psc[0].z, psc[0].w, psc[PV - 1].x, psc[PV - 1].y, psc[PV - 1].z, psc[PV - 1].w};
+              const float sh[8] = {psh[0].x, psh[0].y, psh[0].z, psh[0].w, psh[PV - 1].x, psh[PV - 1].y, psh[PV - 1].z, psh[PV - 1].w};
+#pragma unroll
+              for (int k = 0; k < 8; ++k) e[k] = e[k] * sc[k] + sh[k];
+            }
+            if (lr) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) e[k] = lrelu(e[k]);
+            }
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f32_to_bf16(e[2 * k]) | ((uint32_t)f32_to_bf16(e[2 * k + 1]) << 16);
+            v = make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]), __uint_as_float(o[3]));
+          }
+        } else {
+          if (aff) v = make_float4(v.x * psc[0].x + psh[0].x, v.y * psc[0].y + psh[0].y, v.z * psc[0].z + psh[0].z, v.w * psc[0].w + psh[0].w);
+          if (lr) v = lrelu4(v);
+        }
       }
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       int lpix = pix;
@@ -473,20 +547,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     if constexpr (BF16) {
       {
         // v_mfma_f32_32x32x16_bf16: lane (row/col = l&31, half h = l>>5) holds k = 8h .. 8h+7 of a
-        // 16-channel step: 32 contiguous bytes of the same fp32 LDS rows the fp32 path reads
+        // 16-channel step: 16 contiguous bytes of the bf16 LDS row, one ds_read_b128 and no conversion
+        constexpr int KBW16 = BK / 16 / KW;
 #pragma unroll
-        for (int kb = 0; kb < BK / 16; ++kb) {
+        for (int kj = 0; kj < KBW16; ++kj) {
+          const int kb = kw * KBW16 + kj;
           bf16x8 a[MF], b[NFE];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            const float* q = sA + aoff[mf] + kb * 16 + lh * 8;
-            a[mf] = to_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
-          }
+          for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const bf16x8*>(sA + aoff[mf] + kb * 8 + lh * 4);
 #pragma unroll
-          for (int nf = 0; nf < NFE; ++nf) {
-            const float* q = sBrow + nf * 32 * G::CK + kb * 16 + lh * 8;
-            b[nf] = to_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
-          }
+          for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(sBrow + nf * 32 * G::CK + kb * 8 + lh * 4);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -658,15 +728,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 
   // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----
   if constexpr (AUX && KS == 3 && STRIDE == 1 && !UPS && !SPADE) if (p.x2 != nullptr && split == p.ksplit - 1) {
-    const float* x2n = p.x2 + (size_t)n * p.Hin * p.Win * p.x2C;
+    const char* x2n = reinterpret_cast<const char*>(p.x2) + (size_t)n * p.Hin * p.Win * p.x2C * ESZ;
+    const char* w2b = reinterpret_cast<const char*>(p.w2);
     auto loadB2 = [&](int kc) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        const int row = idx / GPR, c4 = idx % GPR;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(p.w2 + (size_t)(n0 + row) * p.Cin2 + kc + c4 * 4);
+          v = *reinterpret_cast<const float4*>(w2b + ((size_t)(n0 + row) * p.Cin2 + kc + c4 * EPS) * ESZ);
         breg[i] = v;
       }
     };
@@ -676,7 +747,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         int pix, iy, ix;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (slot_inb(i, pix, iy, ix))
-          v = *reinterpret_cast<const float4*>(x2n + (unsigned)((iy * p.Win + ix) * p.x2C + kc + ac4 * 4));
+          v = *reinterpret_cast<const float4*>(x2n + (size_t)(unsigned)((iy * p.Win + ix) * p.x2C + kc + ac4 * EPS) * ESZ);
         areg[i] = v;
       }
     };
@@ -815,7 +886,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
             oy = min(oy, p.Hout - 1); ox = min(ox, p.Wout - 1);
             const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)
                                           : ((size_t)n * p.Hout + oy) * p.Wout + ox;
-            rv[r] = p.res[rpix * p.resC + min(col, p.resC - 1)];
+            rv[r] = ld_act<BF16>(p.res, rpix * p.resC + min(col, p.resC - 1));
           }
         }
         // values first (no memory operations, the activation chosen once per fragment), then the stores: with
@@ -838,6 +909,16 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) vv[r] = 1.f / (1.f + __expf(-vv[r]));
         }
+        float vf[16];       // unrounded values for an fp32 side copy (the image head's NCHW output)
+        if constexpr (BF16) {
+          if (!p.y_f32) {   // the stored tensor is bf16: the statistics describe what the consumer will read
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { vf[r] = vv[r]; vv[r] = bf16_round(vv[r]); }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vf[r] = vv[r];
+          }
+        }
         unsigned okm = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -857,7 +938,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
           int ox = tx0 + row % FRW;
           if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
-          if (okm & (1u << r)) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + col] = vv[r];
+          if (okm & (1u << r)) {
+            const size_t yi = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + col;
+            if constexpr (BF16) { if (p.y_f32) p.y[yi] = vv[r]; else st_act<true>(p.y, yi, vv[r]); }
+            else p.y[yi] = vv[r];
+          }
         }
         if (p.y_nchw) {
 #pragma unroll
@@ -866,7 +951,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
             int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
             int ox = tx0 + row % FRW;
             if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
-            if (okm & (1u << r)) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = vv[r];
+            if (okm & (1u << r)) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = BF16 ? vf[r] : vv[r];
           }
         }
       }
@@ -926,7 +1011,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
           const int ox = min(tx0 + row % FRW, p.Wout - 1);
           const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-          xr[r] = (RIB_EXP & 8) ? 1.f : p.xm[(((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0)];
+          xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -939,7 +1024,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
             const float beta = acc[mf][2 * q + 1][r] + bb;
             float o = (xv * sc + sh) * (1.f + gamma) + beta;
             o = apply_act(o, act);
-            if (!(RIB_EXP & 16) || o == 123.456f) yout[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c] = o;
+            if (!(RIB_EXP & 16) || o == 123.456f) st_act<BF16>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
           }
         }
       }
@@ -1031,6 +1116,7 @@ struct SplitEpiParams {
   int Hout, Wout;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p) {
   __shared__ __attribute__((aligned(16))) float red[2][256][4];
   const int c4n = p.CoutPad / 4;
@@ -1088,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       const int oy = pix / p.Wout, ox = pix % p.Wout;
       const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : (size_t)n * npix + pix;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rres[k][e] = p.res[rpix * p.resC + min(c4 * 4 + e, p.resC - 1)];
+      for (int e = 0; e < 4; ++e) rres[k][e] = ld_act<BF16>(p.res, rpix * p.resC + min(c4 * 4 + e, p.resC - 1));
     }
   }
   float vals[4][4];
@@ -1102,6 +1188,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       float t = v[e];
       if (p.res) t += rres[k][e];
       t = apply_act(t, p.act);
+      if constexpr (BF16) t = bf16_round(t);      // statistics of the tensor as it is stored
       vals[k][e] = (pix < npix && c4 * 4 + e < p.Cout) ? t : 0.f;
     }
     s1.x += vals[k][0]; s1.y += vals[k][1]; s1.z += vals[k][2]; s1.w += vals[k][3];
@@ -1114,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       const size_t opix = (size_t)n * npix + pix;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (c4 * 4 + e < p.Cout) p.y[opix * p.yC + p.yoff + c4 * 4 + e] = vals[k][e];
+        if (c4 * 4 + e < p.Cout) st_act<BF16>(p.y, opix * p.yC + p.yoff + c4 * 4 + e, vals[k][e]);
     }
   }
   if (p.stat_part) {
@@ -1150,6 +1237,7 @@ struct ModulateParams {
   int Hout, Wout;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) {
   const int v4n = p.nsets * p.C / 4;
   const int n = blockIdx.y;
@@ -1177,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
     const int c = v - set * p.C;
     const int oy = pix / p.Wout, ox = pix % p.Wout;
     const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-    const float4 x = *reinterpret_cast<const float4*>(p.xm + (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
+    const float4 x = ld_act4<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
     const float4 sc = *reinterpret_cast<const float4*>(p.m_scale + (size_t)n * p.m_ld + c);
     const float4 sh = *reinterpret_cast<const float4*>(p.m_shift + (size_t)n * p.m_ld + c);
     const int act = set ? p.act1 : p.act0;
@@ -1187,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
     o.z = apply_act((x.z * sc.z + sh.z) * (1.f + (g.z + bg.z)) + (b.z + bb.z), act);
     o.w = apply_act((x.w * sc.w + sh.w) * (1.f + (g.w + bg.w)) + (b.w + bb.w), act);
     float* yout = set ? p.ys1 : p.ys0;
-    *reinterpret_cast<float4*>(yout + ((size_t)n * npix + pix) * p.C + c) = o;
+    st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
   }
 }
 
@@ -1203,6 +1291,7 @@ struct PoolParams {
   int blocks;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
   __shared__ __attribute__((aligned(16))) float red[2][256][4];
   const int c4n = p.C / 4;
@@ -1213,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
   const int npix = Ho * Wo;
   const int ppb = slots * 4;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  const float* xn = p.x + (size_t)n * p.H * p.W * p.C;
+  const size_t xn = (size_t)n * p.H * p.W * p.C;
   for (int k = 0; k < 4; ++k) {
     const int pix = blockIdx.x * ppb + k * slots + slot;
     if (pix < npix && slot < slots) {
@@ -1226,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
         const int iy = oy * 2 - 1 + t / 3, ix = ox * 2 - 1 + t % 3;
         m[t] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
         const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        v[t] = *reinterpret_cast<const float4*>(xn + ((size_t)cy * p.W + cx) * p.C + c4 * 4);
+        v[t] = ld_act4<BF16>(p.x, xn + ((size_t)cy * p.W + cx) * p.C + c4 * 4);
       }
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1234,7 +1323,8 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
         if (m[t] != 0.f) { a.x += v[t].x; a.y += v[t].y; a.z += v[t].z; a.w += v[t].w; }
       const float inv9 = 1.f / 9.f;
       a.x *= inv9; a.y *= inv9; a.z *= inv9; a.w *= inv9;
-      *reinterpret_cast<float4*>(p.y + ((size_t)n * npix + pix) * p.C + c4 * 4) = a;
+      if constexpr (BF16) a = make_float4(bf16_round(a.x), bf16_round(a.y), bf16_round(a.z), bf16_round(a.w));
+      st_act4<BF16>(p.y, ((size_t)n * npix + pix) * p.C + c4 * 4, a);
       s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
       s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
     }
@@ -1266,6 +1356,7 @@ struct InAddParams {
   int ld;   // leading dim of the scale/shift arrays
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
   const int c4n = p.C / 4;
   const size_t total = (size_t)p.HW * c4n;
@@ -1273,20 +1364,20 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c4 = (int)(i % c4n);
     const size_t e = ((size_t)n * p.HW) * p.C + i * 4;
-    const float4 a = *reinterpret_cast<const float4*>(p.t1 + e);
+    const float4 a = ld_act4<BF16>(p.t1, e);
     const float4 s = *reinterpret_cast<const float4*>(p.sc1 + (size_t)n * p.ld + c4 * 4);
     const float4 t = *reinterpret_cast<const float4*>(p.sh1 + (size_t)n * p.ld + c4 * 4);
     float4 o = make_float4(a.x * s.x + t.x, a.y * s.y + t.y, a.z * s.z + t.z, a.w * s.w + t.w);
     if (p.ts) {
-      const float4 b = *reinterpret_cast<const float4*>(p.ts + e);
+      const float4 b = ld_act4<BF16>(p.ts, e);
       const float4 s2 = *reinterpret_cast<const float4*>(p.scs + (size_t)n * p.ld + c4 * 4);
       const float4 t2 = *reinterpret_cast<const float4*>(p.shs + (size_t)n * p.ld + c4 * 4);
       o.x += b.x * s2.x + t2.x; o.y += b.y * s2.y + t2.y; o.z += b.z * s2.z + t2.z; o.w += b.w * s2.w + t2.w;
     } else {
-      const float4 b = *reinterpret_cast<const float4*>(p.xres + e);
+      const float4 b = ld_act4<BF16>(p.xres, e);
       o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
     }
-    *reinterpret_cast<float4*>(p.out + e) = o;
+    st_act4<BF16>(p.out, e, o);
   }
 }
 
@@ -1299,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
 // element) and the CO x 9 x Cin filter in LDS; thread = pixel; filter reads are LDS broadcasts.
 // Uses IgemmParams (x, prologue, w [CoutPad][9][Cin], bias, y / y_nchw, act); grid (tiles, 1, B).
 // ---------------------------------------------------------------------------------------------
-template <int CO>
+template <int CO, bool BF16 = false>
 __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
   const int Cin = p.Cin, CK = Cin + 4, C4 = Cin / 4;
@@ -1309,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
   const int n = blockIdx.z;
   const int tile = p.xcd_chunk ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int ty0 = (tile / p.tilesX) * 16, tx0 = (tile % p.tilesX) * 16;
-  const float* xn = p.x + (size_t)n * p.Hin * p.Win * p.xC;
+  const size_t xn = (size_t)n * p.Hin * p.Win * p.xC;
   for (int i = tid; i < CO * 9 * C4; i += 256)
     *reinterpret_cast<float4*>(sW + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);   // rows 0..CO-1 are contiguous
   const int total4 = 18 * 18 * C4;
@@ -1332,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
       const int idx = min(base + u * 256 + tid, total4 - 1);
       const int pix = idx / C4;
       const int iy = min(max(ty0 - 1 + pix / 18, 0), p.Hin - 1), ix = min(max(tx0 - 1 + pix % 18, 0), p.Win - 1);
-      v[u] = *reinterpret_cast<const float4*>(xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
+      v[u] = ld_act4<BF16>(p.x, xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1371,10 +1462,12 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     const float v = apply_act(acc[co] + bias[co], p.act);
-    p.y[pix * p.yC + p.yoff + co] = v;
+    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v;
     if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
   }
-  for (int co = CO; co < p.Cout; ++co) p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);   // channel padding, as k_igemm stores it
+  for (int co = CO; co < p.Cout; ++co) {   // channel padding, as k_igemm stores it
+    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1403,6 +1496,7 @@ struct PackParams {
   int HW;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_pack(const PackParams p) {
   // 64 pixels per block.  Phase 1: thread = (pixel, channel slice) reads NCHW coalesced along the
   // pixels; phase 2, after an LDS transpose: consecutive lanes write consecutive 16 bytes of NHWC.
@@ -1426,18 +1520,19 @@ __global__ __launch_bounds__(256) void k_pack(const PackParams p) {
   for (int idx = threadIdx.x; idx < 64 * c4n; idx += 256) {
     const int q = idx / c4n, g = idx % c4n;
     if (pix0 + q < p.HW)
-      *reinterpret_cast<float4*>(p.dst + ((size_t)n * p.HW + pix0 + q) * p.dC + g * 4) =
-          make_float4(tile[q][g * 4], tile[q][g * 4 + 1], tile[q][g * 4 + 2], tile[q][g * 4 + 3]);
+      st_act4<BF16>(p.dst, ((size_t)n * p.HW + pix0 + q) * p.dC + g * 4,
+                    make_float4(tile[q][g * 4], tile[q][g * 4 + 1], tile[q][g * 4 + 2], tile[q][g * 4 + 3]));
   }
 }
 
 // NHWC (channel stride sC, first C channels) -> NCHW, for taps / debugging
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_unpack(const float* src, int sC, int C, int HW, int ups, int H, int W, float* dst) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (pix >= HW) return;
   (void)ups; (void)H; (void)W;
-  for (int c = 0; c < C; ++c) dst[((size_t)n * C + c) * HW + pix] = src[((size_t)n * HW + pix) * sC + c];
+  for (int c = 0; c < C; ++c) dst[((size_t)n * C + c) * HW + pix] = ld_act<BF16>(src, ((size_t)n * HW + pix) * sC + c);
 }
 
 // ---------------------------------------------------------------------------------------------

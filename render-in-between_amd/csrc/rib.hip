@@ -37,6 +37,7 @@
 #define RIB_VS(sec, ...) RIB_I_VS(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VSK(sec, ...) RIB_I_VSK(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VB(sec, ...) RIB_I_VB(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VBX(sec, ...) RIB_I_VBX(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
 #undef RIB_V
 #undef RIB_VK
@@ -47,6 +48,7 @@
 #undef RIB_VS
 #undef RIB_VSK
 #undef RIB_VB
+#undef RIB_VBX
 
 using namespace rib;
 
@@ -66,6 +68,15 @@ std::string fmt(const char* f, ...) {
 // channel padding of an activation: 8, 16, or a multiple of 32 (so that every tensor admits the
 // 16- or 32-channel K chunks of the fast kernel variants; the 22-channel label map becomes 32)
 inline int pad8(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : (c + 31) / 32 * 32); }
+// bf16 storage: 16-channel K steps (v_mfma_f32_32x32x16_bf16), so the smallest activation is 16 channels wide
+inline int pad16(int c) { return c <= 16 ? 16 : (c + 31) / 32 * 32; }
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
+inline uint16_t host_bf16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 inline int pick_bk(int cp) { return cp % 32 == 0 ? 32 : (cp % 16 == 0 ? 16 : 8); }
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
@@ -88,6 +99,8 @@ struct ConvDef {
   bool ups_in = false;
   size_t wp_off = 0;
   int cinp = 0, coutp = 0;
+  // bf16 storage mode: bf16 copies of the filters (same [CoutPad][tap][CinPad] layout), offsets in floats of the blob
+  size_t w16_off = 0, wp16_off = 0;
 };
 
 struct TensorDef {
@@ -102,6 +115,7 @@ struct SpadeGroup {   // one SPADE launch: 1 or 2 modulations sharing the normal
   std::string key;    // "<block>.0s" / "<block>.0" / "<block>.1"
   int C = 0, Cp = 0, cond = 0, nsets = 1;
   size_t w_off = 0, b_off = 0;
+  size_t w16_off = 0; // bf16 copy of the gamma/beta filters (bf16 storage mode)
   int npad = 0;       // virtual columns (multiple of 64)
 };
 
@@ -188,7 +202,8 @@ struct Variant {
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
-    const int main_loop = ((TB == 9 ? 2 : 1) * ih * iwp * (BK + 4) + 2 * TB * BN() * (BK + 4)) * 4;   // IgemmGeom::NA
+    const int ck = (BF16 ? BK / 2 : BK) + 4;                                                  // IgemmGeom::CK
+    const int main_loop = ((TB == 9 ? 2 : 1) * ih * iwp * ck + 2 * TB * BN() * ck) * 4;   // IgemmGeom::NA
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
   }
@@ -239,6 +254,9 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW},
 #define RIB_VB(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true},
+#define RIB_VBX(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, true, nullptr, nullptr, KW, TB},
 
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
@@ -262,14 +280,10 @@ struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; }
 Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                          int Cin, bool allow_split, int Cin2, bool allow_n16);
 
-// bf16 handles prefer a bf16 twin and fall back to the fp32 kernels where none exists
 Choice choose_variant(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                       int Cin, bool allow_split, int Cin2 = 0, bool allow_n16 = false) {
-  if (bf16) {
-    Choice c = choose_variant_dt(true, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16);
-    if (c.v) return c;
-  }
-  return choose_variant_dt(false, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16);
+  // a bf16 handle stores bf16 activations: only the bf16 kernels can read them
+  return choose_variant_dt(bf16, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16 && !bf16);
 }
 
 Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
@@ -419,10 +433,13 @@ struct rib_handle {
   std::vector<SpadeGroup> spades;
   std::map<std::string, int> spade_index;
   float* d_blob = nullptr;
+  size_t d_blob_floats = 0;      // allocated size (the bf16 storage mode carries bf16 filter copies: a larger blob)
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
   bool weights_ready = false;
   bool compute_bf16 = false;   // rib_set_compute_dtype
+  int padc(int c) const { return compute_bf16 ? pad16(c) : pad8(c); }   // channel padding of an activation
+  int esz() const { return compute_bf16 ? 2 : 4; }                       // bytes per stored activation / filter element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
@@ -464,11 +481,13 @@ const ConvDef& conv_of(const rib_handle* h, const std::string& name) {
 // ------------------------------------------------------------------------------------------
 void assign_weight_layout(rib_handle* h) {
   size_t off = 0;
+  h->spades.clear(); h->spade_index.clear();
   auto take = [&](size_t nfloats) { size_t o = off; off += (nfloats + 63) / 64 * 64; return o; };
   for (auto& c : h->convs) {
     if (!c.used) continue;
-    c.cinp = pad8(c.cin);
+    c.cinp = h->padc(c.cin);
     c.coutp = pad32(c.cout);
+    c.w16_off = c.wp16_off = 0; c.fb_off = 0;
     c.w_off = take((size_t)c.coutp * c.ks * c.ks * c.cinp);
     if (c.ups_in) c.wp_off = take((size_t)c.coutp * 16 * c.cinp);
     c.b_off = take(c.coutp);
@@ -484,14 +503,22 @@ void assign_weight_layout(rib_handle* h) {
     const std::string which = c.name.substr(c.name.size() - 1);
     if (which == "s") continue;   // folded into the "0" group
     SpadeGroup sg;
-    sg.C = c.cin; sg.Cp = pad8(c.cin); sg.cond = c.spade_cond;
+    sg.C = c.cin; sg.Cp = h->padc(c.cin); sg.cond = c.spade_cond;
     sg.nsets = (which == "0" && h->conv_index.count(blk + ".conv_block_s")) ? 2 : 1;
     sg.key = blk + "." + which;
     sg.npad = (sg.nsets * sg.Cp + 31) / 32 * 64;
-    sg.w_off = take((size_t)sg.npad * pad8(sg.cond));
+    sg.w_off = take((size_t)sg.npad * h->padc(sg.cond));
     sg.b_off = take(sg.npad);
     h->spade_index[sg.key] = (int)h->spades.size();
     h->spades.push_back(sg);
+  }
+  if (h->compute_bf16) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float)
+    for (auto& c : h->convs) {
+      if (!c.used) continue;
+      c.w16_off = take(((size_t)c.coutp * c.ks * c.ks * c.cinp + 1) / 2);
+      if (c.ups_in) c.wp16_off = take(((size_t)c.coutp * 16 * c.cinp + 1) / 2);
+    }
+    for (auto& sg : h->spades) sg.w16_off = take(((size_t)sg.npad * h->padc(sg.cond) + 1) / 2);
   }
   h->blob_floats = off;
 }
@@ -593,8 +620,8 @@ struct Builder {
     return o;
   }
   Act act(int C, int H, int W) {
-    Act a; a.C = C; a.Cp = pad8(C); a.H = H; a.W = W;
-    a.off = alloc((size_t)B * H * W * a.Cp * sizeof(float));
+    Act a; a.C = C; a.Cp = h->padc(C); a.H = H; a.W = W;
+    a.off = alloc((size_t)B * H * W * a.Cp * h->esz());
     return a;
   }
   Norm norm(int Cp) {
@@ -637,14 +664,14 @@ struct Builder {
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
     // the 16-column path serves layers with <= 16 output channels and no residual read
-    const bool can_n16 = c.cout <= 16 && !a.res && !getenv("RIB_NO_N16");
+    const bool can_n16 = c.cout <= 16 && !a.res && !h->compute_bf16 && !getenv("RIB_NO_N16");
     Choice ch = choose_variant(h->compute_bf16, c.stride, c.ks, a.ups, false, c.coutp, TB_(), Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        const bool ok = tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+        const bool ok = tv.BF16 == h->compute_bf16 && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
                         (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
@@ -671,7 +698,7 @@ struct Builder {
     // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
     const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
                        c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
-                       !h->compute_bf16 && !getenv("RIB_NO_SMALLCONV");
+                       !getenv("RIB_NO_SMALLCONV");
     if (a.pro) {
       // consumer-side finalize: this launch reduces the producer's partial sums in its prologue
       if (has_partials(*a.pro) && a.pro_choff == 0 && !small && c.cinp <= STATS_MAX_PRO_CH && c.cinp <= a.pro->pend->Cs) {
@@ -683,20 +710,22 @@ struct Builder {
         op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float));
       }
     }
-    op.w = WT(a.ups ? c.wp_off : c.w_off); op.bias = WT(c.b_off);
+    // matrix-core kernels of a bf16 handle read the bf16 filter copies; the direct head convolutions keep fp32 filters
+    const bool w16 = h->compute_bf16 && !small;
+    op.w = WT(a.ups ? (w16 ? c.wp16_off : c.wp_off) : (w16 ? c.w16_off : c.w_off)); op.bias = WT(c.b_off);
     double aux_flops = 0.0;
     if (a.aux) {
       if (c.ks != 3 || c.stride != 1 || a.ups || !c.fb_off || a.aux->ks != 1 || a.aux->coutp != c.coutp || a.aux_in.Cp != a.aux->cinp ||
           a.aux_in.H != Hout || a.aux_in.W != Wout) { error = opname + ": fused shortcut operand does not fit"; return false; }
-      op.x2 = WS(a.aux_in.off); op.w2 = WT(a.aux->w_off); op.bias = WT(c.fb_off);
+      op.x2 = WS(a.aux_in.off); op.w2 = WT(h->compute_bf16 ? a.aux->w16_off : a.aux->w_off); op.bias = WT(c.fb_off);
       p.x2C = a.aux_in.Cp; p.Cin2 = a.aux->cinp;
       aux_flops = 2.0 * a.aux->cin * a.aux->cout * (double)Hout * Wout * B;
     }
     if (a.y_user.sp != PS_NULL) {
-      op.y = a.y_user; p.yC = c.cout; p.yoff = 0; p.Cout = c.cout;
+      op.y = a.y_user; p.yC = c.cout; p.yoff = 0; p.Cout = c.cout; p.y_f32 = 1;   // a caller's fp32 tensor
     } else {
       op.y = WS(a.out.off); p.yC = a.out.Cp; p.yoff = a.yoff;
-      p.Cout = a.cout_store >= 0 ? a.cout_store : pad8(c.cout);
+      p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
       if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
@@ -741,7 +770,7 @@ struct Builder {
     if (a.want_stats) {
       Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
       memset(&f.fp, 0, sizeof f.fp);
-      f.fp.tiles = tiles; f.fp.Cs = c.coutp; f.fp.C = pad8(c.cout);
+      f.fp.tiles = tiles; f.fp.Cs = c.coutp; f.fp.C = h->padc(c.cout);
       f.fp.ld = a.stats_out->ld; f.fp.off = (int)a.stats_choff;
       f.fp.inv_count = 1.0f / ((float)Hout * (float)Wout); f.fp.eps = 1e-5f;
       f.f_part = WS(part_off);
@@ -761,7 +790,7 @@ struct Builder {
     const SpadeGroup& sg = h->spades[h->spade_index.at(key)];
     const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
-    if (cond.Cp != pad8(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
+    if (cond.Cp != h->padc(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
     if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
     // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
     // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
@@ -776,7 +805,7 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        if (tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
+        if (tv.BF16 != h->compute_bf16 || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
           error = key + ": tuned SPADE choice does not fit"; return false;
         }
         if (tv.SPADE) { v = &tv; unfused = false; }
@@ -796,7 +825,7 @@ struct Builder {
       p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
       p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
       p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
-      op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
+      op.x = WS(cond.off); op.w = WT(h->compute_bf16 ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
       op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
       op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
       P->flops[RIB_KC_SPADE] += op.flops;
@@ -824,7 +853,7 @@ struct Builder {
     p.ksplit = 1;
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
-    op.x = WS(cond.off); op.w = WT(sg.w_off); op.bias = WT(sg.b_off);
+    op.x = WS(cond.off); op.w = WT(h->compute_bf16 ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off);
     op.xm = WS(x.off);
     if (has_partials(nx) && !nx.pend->affine && sg.Cp <= nx.pend->Cs) {   // consumer-side finalize in the SPADE epilogue
       const PendingStats& ps = *nx.pend;
@@ -891,7 +920,7 @@ struct Builder {
       const ConvDef& cd = conv_of(h, m + "." + branches[b] + "." + std::to_string(i));
       const bool lastl = (i == c.mask_down);
       Act o = lastl ? CAT : act(cd.cout, i == 0 ? cur.H : cur.H / 2, i == 0 ? cur.W : cur.W / 2);
-      Norm no = lastl ? ncat : norm(pad8(cd.cout));
+      Norm no = lastl ? ncat : norm(h->padc(cd.cout));
       ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
       if (have) { a.pro = &ncur; a.pro_lrelu = true; }
       if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; }
@@ -970,9 +999,9 @@ struct Builder {
 
   void record_label_slots(const Act& x, const Norm& nx, const Act& CAT, const Norm& ncat) {
     LabelSlots& l = P->ls;
-    l.x0 = x.off; l.x0_b = (size_t)B * x.H * x.W * x.Cp * sizeof(float);
+    l.x0 = x.off; l.x0_b = (size_t)B * x.H * x.W * x.Cp * h->esz();
     l.nx_sc = nx.sc; l.nx_sh = nx.sh; l.nx_b = (size_t)B * nx.ld * sizeof(float);
-    l.cat = CAT.off; l.cat_b = (size_t)B * CAT.H * CAT.W * CAT.Cp * sizeof(float);
+    l.cat = CAT.off; l.cat_b = (size_t)B * CAT.H * CAT.W * CAT.Cp * h->esz();
     l.ncat_sc = ncat.sc; l.ncat_sh = ncat.sh; l.ncat_b = (size_t)B * ncat.ld * sizeof(float);
   }
 
@@ -995,7 +1024,7 @@ struct Builder {
       push(op);
     }
     const int chm = g.mask_nf(c.mask_down);
-    if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
+    if (h->padc(chm) != chm) { error = "mask network width must be a multiple of 8 (16 with bf16 storage)"; return false; }
     Act CAT = act(2 * chm, H >> c.mask_down, W >> c.mask_down);
     Norm ncat = norm(CAT.Cp);
     if (!mask_branch(0, L, CAT, ncat, chm)) return false;
@@ -1062,7 +1091,7 @@ struct Builder {
     const std::string m = "flow_network_temp";
     const int chm = g.mask_nf(c.mask_down);
     const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
-    if (pad8(chm) != chm) { error = "mask network width must be a multiple of 8"; return false; }
+    if (h->padc(chm) != chm) { error = "mask network width must be a multiple of 8 (16 with bf16 storage)"; return false; }
     Act CAT = act(2 * chm, Hm, Wm);
     Norm ncat = norm(CAT.Cp);
     int ev_lbl = -1;
@@ -1258,6 +1287,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
       HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       h->events.push_back(e);
     }
+  const bool bf16 = h->compute_bf16;
   for (Op& op : P->ops) {
     if (skip_label_ops && op.label_only) continue;     // done for the whole chain by the labels-only plan
     // in single-stream mode the plan order is already a valid topological order
@@ -1283,7 +1313,12 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.m_part = R.get<const float>(op.m_part);
         if (op.small_co > 0) {
           const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
-          switch (op.small_co) {
+          if (bf16) switch (op.small_co) {
+            case 1: hipLaunchKernelGGL((k_conv_small<1, true>), op.grid, dim3(256), lds, st, p); break;
+            case 2: hipLaunchKernelGGL((k_conv_small<2, true>), op.grid, dim3(256), lds, st, p); break;
+            case 3: hipLaunchKernelGGL((k_conv_small<3, true>), op.grid, dim3(256), lds, st, p); break;
+            default: hipLaunchKernelGGL((k_conv_small<4, true>), op.grid, dim3(256), lds, st, p); break;
+          } else switch (op.small_co) {
             case 1: hipLaunchKernelGGL(k_conv_small<1>, op.grid, dim3(256), lds, st, p); break;
             case 2: hipLaunchKernelGGL(k_conv_small<2>, op.grid, dim3(256), lds, st, p); break;
             case 3: hipLaunchKernelGGL(k_conv_small<3>, op.grid, dim3(256), lds, st, p); break;
@@ -1303,31 +1338,36 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.slab = R.get<const float>(op.m_slab); p.bias = R.get<const float>(op.m_bias); p.xm = R.get<const float>(op.m_xm);
         p.m_scale = R.get<const float>(op.m_sc); p.m_shift = R.get<const float>(op.m_sh);
         p.ys0 = R.get<float>(op.m_ys0); p.ys1 = R.get<float>(op.m_ys1);
-        hipLaunchKernelGGL(k_spade_modulate, op.grid, dim3(256), 0, st, p);
+        if (bf16) hipLaunchKernelGGL(k_spade_modulate<true>, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_spade_modulate<false>, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_SPLITEPI: {
         SplitEpiParams p = op.sp;
         p.slab = R.get<const float>(op.s_slab); p.bias = R.get<const float>(op.s_bias); p.y = R.get<float>(op.s_y);
         p.res = R.get<const float>(op.s_res); p.stat_part = R.get<float>(op.s_stat);
-        hipLaunchKernelGGL(k_splitk_epilogue, op.grid, dim3(256), 0, st, p);
+        if (bf16) hipLaunchKernelGGL(k_splitk_epilogue<true>, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_splitk_epilogue<false>, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_POOL: {
         PoolParams p = op.pp;
         p.x = R.get<const float>(op.p_x); p.y = R.get<float>(op.p_y); p.stat_part = R.get<float>(op.p_stat);
-        hipLaunchKernelGGL(k_avgpool, op.grid, dim3(256), 0, st, p);
+        if (bf16) hipLaunchKernelGGL(k_avgpool<true>, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_avgpool<false>, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_INADD: {
         InAddParams p = op.ap;
         p.t1 = R.get<const float>(op.a_t1); p.sc1 = R.get<const float>(op.a_sc1); p.sh1 = R.get<const float>(op.a_sh1);
         p.ts = R.get<const float>(op.a_ts); p.scs = R.get<const float>(op.a_scs); p.shs = R.get<const float>(op.a_shs);
         p.xres = R.get<const float>(op.a_x); p.out = R.get<float>(op.a_out);
-        hipLaunchKernelGGL(k_in_add, op.grid, dim3(256), 0, st, p);
+        if (bf16) hipLaunchKernelGGL(k_in_add<true>, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_in_add<false>, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_PACK: {
         PackParams p = op.kp;
         p.s0 = R.get<const float>(op.k_s0); p.s1 = R.get<const float>(op.k_s1); p.s2 = R.get<const float>(op.k_s2);
         p.dst = R.get<float>(op.k_dst);
-        hipLaunchKernelGGL(k_pack, op.grid, dim3(256), 0, st, p);
+        if (bf16) hipLaunchKernelGGL(k_pack<true>, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_pack<false>, op.grid, dim3(256), 0, st, p);
       } break;
     }
     if (h->profiling) {
@@ -1381,6 +1421,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
   if (device >= 0) {   // device < 0: host-only handle (inventory, plans, weight fold; no launches)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float));
+    h->d_blob_floats = h->blob_floats;
     // Side streams are opt-in (RIB_STREAMS="i,j" picks two of a small pool for the condition encoder
     // and the label branch): HIP multiplexes streams onto a few hardware queues and a side stream
     // that lands on the caller's queue only adds event traffic (stream_overlap_probe.py).
@@ -1514,7 +1555,7 @@ int rib_finalize_weights(rib_handle* h) {
   for (auto& sg : h->spades) {
     const std::string blk = sg.key.substr(0, sg.key.size() - 2);
     const std::string which = sg.key.substr(sg.key.size() - 1);
-    const int condp = pad8(sg.cond);
+    const int condp = h->padc(sg.cond);
     for (int set = 0; set < sg.nsets; ++set) {
       const std::string cn = blk + ".conv_block_" + (set == 0 ? which : std::string("s"));
       const std::string sp = cn + ".layers.norm.mlps.0.0.layers.conv";
@@ -1532,10 +1573,28 @@ int rib_finalize_weights(rib_handle* h) {
       }
     }
   }
+  if (h->compute_bf16) {
+    auto to16 = [&](size_t src, size_t dst, size_t n) {
+      uint16_t* d = reinterpret_cast<uint16_t*>(&blob[dst]);
+      for (size_t i = 0; i < n; ++i) d[i] = host_bf16(blob[src + i]);
+    };
+    for (auto& c : h->convs) {
+      if (!c.used) continue;
+      to16(c.w_off, c.w16_off, (size_t)c.coutp * c.ks * c.ks * c.cinp);
+      if (c.ups_in) to16(c.wp_off, c.wp16_off, (size_t)c.coutp * 16 * c.cinp);
+    }
+    for (auto& sg : h->spades) to16(sg.w_off, sg.w16_off, (size_t)sg.npad * h->padc(sg.cond));
+  }
   if (h->device < 0) {
     h->host_blob.swap(blob);
   } else {
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->d_blob_floats != h->blob_floats) {
+      if (h->d_blob) (void)hipFree(h->d_blob);
+      h->d_blob = nullptr; h->d_blob_floats = 0;
+      HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float)));
+      h->d_blob_floats = h->blob_floats;
+    }
     HIP_TRY(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->weights_ready = true;
   }
@@ -1560,6 +1619,12 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
   if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
   if (h->device < 0) return fail(h, RIB_ERR_INVALID, "rib_import_weights: host-only handle");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (h->d_blob_floats != h->blob_floats) {
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    h->d_blob = nullptr; h->d_blob_floats = 0;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float)));
+    h->d_blob_floats = h->blob_floats;
+  }
   HIP_TRY(h, hipMemcpyAsync(h->d_blob, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
   h->weights_ready = true;
   return RIB_OK;
@@ -1567,8 +1632,22 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
   if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
-  if (h->compute_bf16 != (dtype == RIB_DTYPE_BF16)) h->plans.clear();   // kernels are chosen per dtype
+  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16)) return RIB_OK;
+  // The storage type decides the activation / filter layout (bf16: 16-channel minimum, bf16 filter copies in the
+  // blob): plans and the weight layout are rebuilt, and the folded blob has to be produced again - by
+  // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
+  // exported by a handle of the same storage type.
+  h->plans.clear();
   h->compute_bf16 = dtype == RIB_DTYPE_BF16;
+  assign_weight_layout(h);
+  const bool had = h->weights_ready || !h->host_blob.empty();
+  h->weights_ready = false;
+  h->host_blob.clear();
+  if (had) {
+    bool all = true;
+    for (auto& t : h->tensors) all = all && t.set && (!t.used || !t.data.empty());
+    if (all) return rib_finalize_weights(h);
+  }
   return RIB_OK;
 }
 
@@ -1812,7 +1891,8 @@ int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* worksp
   const Tap& t = P->taps[idx];
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + t.off);
-  hipLaunchKernelGGL(k_unpack, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
+  if (h->compute_bf16) hipLaunchKernelGGL(k_unpack<true>, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
+  else hipLaunchKernelGGL(k_unpack<false>, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(st));
   return RIB_OK;
@@ -1848,7 +1928,7 @@ int rib_debug_spade_weight(rib_handle* h, const char* conv_name, float* w_2c_by_
   if (it == h->spade_index.end()) return fail(h, RIB_ERR_INVALID, fmt("no SPADE group '%s'", key.c_str()));
   const SpadeGroup& sg = h->spades[it->second];
   const int set = which == "s" ? 1 : 0;
-  const int condp = pad8(sg.cond);
+  const int condp = h->padc(sg.cond);
   for (int ch = 0; ch < sg.C; ++ch) {
     const int v = set * sg.Cp + ch;
     const int colg = (v / 32) * 64 + (v % 32), colb = colg + 32;

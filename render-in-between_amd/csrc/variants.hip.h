@@ -42,3 +42,6 @@
 #define RIB_I_VS(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false)
 #define RIB_I_VSK(F, FRW, WM, WN, MF, NF, BK, KW) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW)
 #define RIB_I_VB(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true)
+// bf16-storage variant with explicit wave groups / slices per barrier (one instantiation: shortcut loop where it can exist, prologue)
+#define RIB_I_VBX(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)

@@ -168,7 +168,7 @@ class Generator:
             if self._use_tuning:
                 from . import tuning
                 if self._tuning is None:
-                    self._tuning = tuning.load()
+                    self._tuning = tuning.load(bf16=(self.compute_dtype == "bf16"))
                 tuning.apply(self._lib, self._h, self._tuning, B, H, W, bf16=(self.compute_dtype == "bf16"))
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (B, H, W)):

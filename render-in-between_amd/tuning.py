@@ -9,9 +9,12 @@ import json
 import os
 
 TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+TUNING_PATH_BF16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950_bf16.json")   # measured on the bf16-storage kernels
 
 
-def load(path=TUNING_PATH):
+def load(path=None, bf16=False):
+    if path is None:
+        path = TUNING_PATH_BF16 if bf16 else TUNING_PATH
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
@@ -19,6 +22,7 @@ def load(path=TUNING_PATH):
 
 
 def save(table, path=TUNING_PATH):
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
 

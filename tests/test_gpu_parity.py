@@ -271,26 +271,48 @@ def test_driver_lanes_are_bit_identical(tmp_path):
         assert np.array_equal(np.asarray(Image.open(fa)), np.asarray(Image.open(fb))), fa
 
 
-def test_bf16_matrix_core_mode_error_is_bounded():
-    """BASELINE configs[2] mode: bf16 MFMA operands, fp32 accumulate/statistics/storage.  The
-    tolerance is this mode's own (SURVEY §8c: a pure-bf16 torch forward deviates 1e-1 / 2e-2);
-    the measured error is written to gpurun_out/ for DESIGN.md."""
+def test_bf16_storage_mode_error_is_bounded():
+    """BASELINE configs[2] mode: bf16 NHWC activations and filters in HBM / LDS, bf16 matrix-core operands, fp32
+    accumulation, fp32 InstanceNorm statistics (of the rounded tensors) and fp32 SPADE arithmetic.  The reference has
+    no counterpart (fp32 only), so the tolerance is this mode's own: every stored tensor is rounded to 8 mantissa bits
+    (2^-9 relative) and the error grows to ~1.5 % over the ~40 layers of the deepest path (tools/bf16_debug.py);
+    a pure-bf16 torch forward deviates 1e-1 / 2e-2.  The measured error is written to gpurun_out/."""
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
     sd = synth.make_state_dict(spec, 0)
     G = rib.Generator(cfg, compute_dtype="bf16").eval()
     G.load_state_dict(sd)
-    label, fake, prev = synth.make_inputs(spec, 1, 256, 256, 2)
-    img, mask = G(label, None, fake, prev)
-    oimg, omask = oracle(spec, sd)(label, None, fake, prev)
-    d_img = float((img.cpu() - oimg).abs().max()); d_mask = float((mask.cpu() - omask).abs().max())
-    m_img = float((img.cpu() - oimg).abs().mean()); m_mask = float((mask.cpu() - omask).abs().mean())
+    R = oracle(spec, sd)
+    rep = {}
+    for (B, H, W, seed) in ((1, 256, 256, 2), (2, 48, 80, 3), (1, 16, 16, 4)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        img, mask = G(label, None, fake, prev)
+        assert img.dtype == torch.float32 and mask.dtype == torch.float32          # the boundary stays fp32 NCHW
+        oimg, omask = R(label, None, fake, prev)
+        d_img = float((img.cpu() - oimg).abs().max()); d_mask = float((mask.cpu() - omask).abs().max())
+        m_img = float((img.cpu() - oimg).abs().mean()); m_mask = float((mask.cpu() - omask).abs().mean())
+        rep["%dx%dx%d" % (B, H, W)] = {"max_abs_img": d_img, "max_abs_mask": d_mask, "mean_abs_img": m_img, "mean_abs_mask": m_mask}
+        if H >= 48:      # (a 1x1 deepest map makes InstanceNorm degenerate: compared loosely in fp32 too)
+            assert d_img <= 2e-1 and d_mask <= 8e-2 and m_img <= 2e-2 and m_mask <= 1e-2, (B, H, W, d_img, d_mask, m_img, m_mask)
+        assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(mask).all())
     with open("gpurun_out/parity_bf16_256.json", "w") as f:
-        json.dump({"max_abs_img": d_img, "max_abs_mask": d_mask, "mean_abs_img": m_img, "mean_abs_mask": m_mask}, f)
-    assert d_img <= 1e-1 and d_mask <= 5e-2 and m_img <= 1e-2 and m_mask <= 5e-3, (d_img, d_mask, m_img, m_mask)
+        json.dump(rep, f)
+    # deterministic, and a bf16 handle fed only the exported blob of another bf16 handle reproduces it bit for bit
+    label, fake, prev = synth.make_inputs(spec, 1, 64, 64, 5)
+    a = [t.clone() for t in G(label, None, fake, prev)]
+    b = G(label, None, fake, prev)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    G2 = rib.Generator(cfg, compute_dtype="bf16").import_weights(G.export_weights())
+    c = G2(label, None, fake, prev)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    from render_in_between_amd import _native
+    with pytest.raises(_native.RibError):                                          # an fp32 handle's blob has another layout
+        rib.Generator(cfg).import_weights(G.export_weights())
     # the fp32 default is untouched by the existence of the mode
     G32 = rib.Generator(cfg).eval(); G32.load_state_dict(sd)
+    label, fake, prev = synth.make_inputs(spec, 1, 256, 256, 2)
     i32, m32 = G32(label, None, fake, prev)
+    oimg, omask = R(label, None, fake, prev)
     assert float((i32.cpu() - oimg).abs().max()) <= TOL
 
 
