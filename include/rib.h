@@ -88,12 +88,20 @@ size_t rib_weights_bytes(const rib_handle* h);
 int rib_export_weights(rib_handle* h, void* dst_device, size_t bytes, void* hip_stream);
 int rib_import_weights(rib_handle* h, const void* src_device, size_t bytes, void* hip_stream);
 
-/* ---- arithmetic of the matrix-core contractions (no reference counterpart: the reference is fp32
- * only).  RIB_DTYPE_F32 (default): exact-fp32 MFMA, the mode every parity claim and the bench
- * headline are made in.  RIB_DTYPE_BF16 (BASELINE.json configs[2]): operands rounded to bf16 at the
- * matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulation; activations, InstanceNorm statistics,
- * SPADE modulation and all epilogues stay fp32.  Takes effect on the next forward. ---- */
-enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1 };
+/* ---- storage type and arithmetic of the matrix-core contractions (no reference counterpart: the reference is
+ * fp32 only; PGNR/models/trainer.py:51 builds a plain fp32 module).
+ *   RIB_DTYPE_F32 (default)  fp32 activations and filters, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the mode every
+ *                            parity claim and the bench headline are made in.
+ *   RIB_DTYPE_BF16           BASELINE.json configs[2]: bf16 NHWC activations and bf16 filters in HBM and LDS, bf16
+ *                            MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 InstanceNorm statistics
+ *                            and SPADE arithmetic; the caller's tensors stay fp32 NCHW.
+ *   RIB_DTYPE_F32X3          exploratory: fp32 storage; every MFMA operand is split into three bf16 terms (24
+ *                            significant bits) and each 16-channel step runs six bf16 MFMAs - fp32-grade products at
+ *                            3/8 of the matrix-core time.  Reported beside the fp32 mode, never instead of it.
+ * The mode decides the weight-blob layout (bf16 / three-plane filter copies are appended): set it before
+ * rib_finalize_weights / rib_import_weights (a handle that still holds the state-dict tensors re-folds by itself);
+ * blobs are exchangeable only between handles of the same mode. ---- */
+enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1, RIB_DTYPE_F32X3 = 2 };
 int rib_set_compute_dtype(rib_handle* h, int dtype);
 
 /* ---- forward: replaces  img, mask = net_G(label, label_prev, img_fake, img_prev)
@@ -187,7 +195,7 @@ int rib_num_launches(rib_handle* h, int B, int H, int W);
  * pinned per (B,H,W, op name).  geom = {FRW,WM,WN,MF,NF,BK,STRIDE,KS,UPS,SPADE,KW,TB} (KW: wave
  * groups per workgroup, in-workgroup split-K; TB: filter slices staged per barrier). ---- */
 int rib_num_variants(void);
-int rib_variant_info(int idx, int geom[12]);   /* returns 1 for a bf16 matrix-core twin, 0 for fp32, <0 on error */
+int rib_variant_info(int idx, int geom[12]);   /* returns the precision of the instantiation (RIB_DTYPE_*), <0 on error */
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit);
 int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label,
                 const float* img_fake, const float* img_prev, float* img, float* mask, void* workspace,

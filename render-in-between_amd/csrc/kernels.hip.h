@@ -182,8 +182,14 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
 // WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, bool BF16 = false>
+// PREC: 0 = fp32 (exact-fp32 matrix cores), 1 = bf16 storage + bf16 matrix cores, 2 = "f32x3": fp32 storage, every
+// operand split into three bf16 terms on the way into LDS (x = hi + mid + lo, each the bf16 rounding of what the
+// previous ones left: 24 significant bits) and six bf16 MFMAs per 16-channel step (hi*hi, hi*mid, mid*hi, mid*mid,
+// hi*lo, lo*hi; the dropped terms are below 2^-26 of the product) - fp32-grade products at 3/8 of the matrix time.
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F32X3 = 2 };
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, int PREC = 0>
 struct IgemmGeom {
+  static constexpr bool BF16 = PREC == PREC_BF16, X3 = PREC == PREC_F32X3;
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
   static constexpr int TH = FRH * MF * WM;
@@ -194,9 +200,10 @@ struct IgemmGeom {
   static constexpr int PH = UPS ? 4 : 1;
   static constexpr int IH = UPS ? (TH + 2) : ((TH - 1) * STRIDE + KS);
   static constexpr int IW = UPS ? (TW + 2) : ((TW - 1) * STRIDE + KS);
-  static constexpr int EPS = BF16 ? 8 : 4;     // elements per 16-byte staging slot
-  static constexpr int KF = BK * 4 / EPS;      // floats of LDS one pixel's / filter row's K chunk takes (bf16: BK / 2)
-  static constexpr int GPR = KF / 4;           // 16-byte slots per row
+  static constexpr int EPS = BF16 ? 8 : 4;     // activation elements per 16-byte staging slot
+  static constexpr int KF = X3 ? 3 * BK / 2 : BK * 4 / EPS;   // floats of LDS one pixel's / filter row's K chunk takes (bf16: BK / 2, f32x3: three bf16 planes)
+  static constexpr int GPR = BK / EPS;         // 16-byte global loads per input pixel and chunk
+  static constexpr int GPRB = KF / 4;          // 16-byte global loads (= LDS slots) per filter row and slice
   static constexpr int CK = KF + 4;            // padded LDS row: conflict-free ds_read_b128
   // Stride 2: the halo tile is stored with even and odd columns de-interleaved (column x -> (x & 1) * IWH + x / 2),
   // so that the 16 lanes of a ds_read_b128 phase, which step 2 pixels in x, read consecutive LDS pixels as in the
@@ -210,7 +217,7 @@ struct IgemmGeom {
   static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
   static constexpr int SA = IH * IWP * CK;     // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
-  static constexpr int NB4 = (BN * GPR + NT - 1) / NT;     // 16-byte filter loads per thread per tap
+  static constexpr int NB4 = (BN * GPRB + NT - 1) / NT;    // 16-byte filter loads per thread per tap
   static constexpr int SRED = WM * BN * 2;
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   static constexpr int NA = TB == 9 ? 2 : 1;   // TB = 9 also double-buffers the input tile: one barrier per chunk
@@ -238,21 +245,24 @@ struct IgemmGeom {
 // row -1 / H is exactly where the upsampled row -1 / 2H falls).  A workgroup owns a TH x TW tile of
 // SOURCE pixels and keeps four accumulator sets, one per phase; filter slice t = phase*4 + a*2 + b
 // multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, bool BF16 = false,
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, int PREC = 0,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
 __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
-  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, BF16> G;
-  constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored element (activations and filters)
-  constexpr int EPS = G::EPS, GPR = G::GPR;
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC> G;
+  constexpr bool BF16 = G::BF16, X3 = G::X3;
+  constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored activation element
+  constexpr int WSZ = (BF16 || X3) ? 2 : 4;     // bytes per stored filter element
+  constexpr int EPS = G::EPS, GPR = G::GPR, GPRB = G::GPRB;
+  constexpr int EPB = 16 / WSZ;                 // filter elements per 16-byte slot
   static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS),
                 "filter slices per barrier: one tap, one row of a 3x3 filter, all nine; phase convolutions: the four taps of a phase");
   constexpr int NT = G::NT;
-  static_assert(KW == 1 || (NF > 0 && (BK / (BF16 ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
+  static_assert(KW == 1 || (NF > 0 && (BK / ((BF16 || X3) ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
-  static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0 && !BF16), "16-column path: 8x16-style tiles only, fp32");
+  static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0 && PREC == PREC_F32), "16-column path: 8x16-style tiles only, fp32");
   static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && (TB == 1 || TB == 4) && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
   constexpr int PH = G::PH;
   static_assert(NT % GPR == 0, "a thread keeps one channel group across its staging slots");
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 
   f32x16 acc[PH * MF][NFE];   // UPS: accumulator set ph*MF + mf belongs to phase ph = py*2 + px
   // experiment (RIB_EXP bit 2): two interleaved accumulation chains for single-fragment waves
-  constexpr bool DUAL = (RIB_EXP & 4) && !BF16 && !N16 && !UPS && MF * NFE == 1;
+  constexpr bool DUAL = (RIB_EXP & 4) && PREC == PREC_F32 && !N16 && !UPS && MF * NFE == 1;
   f32x16 accb;
   if (DUAL) {
 #pragma unroll
@@ -319,7 +329,13 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 
   const char* xn = reinterpret_cast<const char*>(p.x) + (size_t)n * p.Hin * p.Win * p.xC * ESZ;
   const char* wb = reinterpret_cast<const char*>(p.w);
-  const int wrow = G::TAPS * p.Cin;   // elements per filter row
+  const int wrow = G::TAPS * p.Cin;   // elements per filter row (f32x3: per plane)
+  // byte offset of the 16-byte slot g of filter row `row`, slice `tap`, chunk kc.  fp32 / bf16: [row][tap][Cin];
+  // f32x3: [row][tap][plane][Cin] bf16, slot g = plane * (BK / 8) + group
+  auto w_off = [&](int row, int tap, int kc, int g) -> size_t {
+    if constexpr (X3) return (((size_t)row * G::TAPS * 3 + tap * 3 + g / (BK / 8)) * p.Cin + kc + (g % (BK / 8)) * 8) * 2;
+    else return ((size_t)row * wrow + tap * p.Cin + kc + g * EPB) * WSZ;
+  };
 
   // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
   // filter slice / input chunk are in flight while the current one feeds the matrix cores ----
@@ -328,11 +344,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
       const int idx = tid + i * NT;
-      const int row = idx / GPR, c4 = idx % GPR;
+      const int row = idx / GPRB, c4 = idx % GPRB;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < G::BN && n0 + row < p.CoutPad)
         v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
-                          : *reinterpret_cast<const float4*>(wb + ((size_t)(n0 + row) * wrow + tap * p.Cin + kc + c4 * EPS) * ESZ);
+                          : *reinterpret_cast<const float4*>(wb + w_off(n0 + row, tap, kc, c4));
       breg[i] = v;
     }
   };
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
       const int idx = tid + i * NT;
-      const int row = idx / GPR, c4 = idx % GPR;
+      const int row = idx / GPRB, c4 = idx % GPRB;
       if (row < G::BN)
         *reinterpret_cast<float4*>(sB + buf * G::SB + row * G::CK + c4 * 4) = breg[i];
     }
@@ -352,10 +368,10 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / GPR, c4 = idx % GPR;
+        const int row = idx / GPRB, c4 = idx % GPRB;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(wb + ((size_t)(n0 + row) * wrow + (dy * (TB == 4 ? 4 : 3) + t) * p.Cin + kc + c4 * EPS) * ESZ);
+          v = *reinterpret_cast<const float4*>(wb + w_off(n0 + row, dy * (TB == 4 ? 4 : 3) + t, kc, c4));
         breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / GPR, c4 = idx % GPR;
+        const int row = idx / GPRB, c4 = idx % GPRB;
         if (row < G::BN)
           *reinterpret_cast<float4*>(sB + (buf * (TB > 1 ? TB : 3) + t) * G::SB + row * G::CK + c4 * 4) = breg[(TB > 1 ? t : 0) * G::NB4 + i];
       }
@@ -457,6 +473,25 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       int lpix = pix;
       if constexpr (STRIDE == 2) { const int ly = pix / G::IW, lx = pix % G::IW; lpix = ly * G::IWP + (lx & 1) * G::IWH + (lx >> 1); }
+      if constexpr (X3) {
+        // three bf16 planes per pixel row: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (the subtractions are exact)
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint16_t hb = f32_to_bf16(e[k]);
+          const float r1 = e[k] - bf16_to_f32(hb);
+          const uint16_t mb = f32_to_bf16(r1);
+          const float r2 = r1 - bf16_to_f32(mb);
+          hi[k] = hb; mi[k] = mb; lo[k] = f32_to_bf16(r2);
+        }
+        if (tid + i * NT < total4) {
+          float* dst = sA + lpix * G::CK + ac4 * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          *reinterpret_cast<uint2*>(dst + BK / 2) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+          *reinterpret_cast<uint2*>(dst + BK) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        }
+      } else
       if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + lpix * G::CK + ac4 * 4) = v;
     }
   };
@@ -543,7 +578,37 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       aoff[mf] = (r * G::IWP + c) * G::CK;
     }
     const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
-    static_assert(!BF16 || (BK % 16 == 0 && NF > 0), "bf16 matrix-core path: 16-channel steps, 32-column fragments");
+    static_assert(!(BF16 || X3) || (BK % 16 == 0 && NF > 0), "bf16 matrix-core paths: 16-channel steps, 32-column fragments");
+    if constexpr (X3) {
+      constexpr int KBW16 = BK / 16 / KW;
+#pragma unroll
+      for (int kj = 0; kj < KBW16; ++kj) {
+        const int kb = kw * KBW16 + kj;
+        bf16x8 a[MF][3], b[NFE][3];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[mf][pl] = *reinterpret_cast<const bf16x8*>(sA + aoff[mf] + pl * (BK / 2) + kb * 8 + lh * 4);
+#pragma unroll
+        for (int nf = 0; nf < NFE; ++nf)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[nf][pl] = *reinterpret_cast<const bf16x8*>(sBrow + nf * 32 * G::CK + pl * (BK / 2) + kb * 8 + lh * 4);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NFE; ++nf) {
+            f32x16& d = acc[ph * MF + mf][nf];
+            // small terms first, the hi*hi term last
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][2], b[nf][0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][2], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][1], b[nf][1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][1], b[nf][0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][0], d, 0, 0, 0);
+          }
+      }
+      return;
+    }
     if constexpr (BF16) {
       {
         // v_mfma_f32_32x32x16_bf16: lane (row/col = l&31, half h = l>>5) holds k = 8h .. 8h+7 of a
@@ -734,10 +799,14 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < G::NB4; ++i) {
         const int idx = tid + i * NT;
-        const int row = idx / GPR, c4 = idx % GPR;
+        const int row = idx / GPRB, c4 = idx % GPRB;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(w2b + ((size_t)(n0 + row) * p.Cin2 + kc + c4 * EPS) * ESZ);
+        if (row < G::BN && n0 + row < p.CoutPad) {
+          size_t off;      // w2 [CoutPad][Cin2] (f32x3: [CoutPad][plane][Cin2] bf16)
+          if constexpr (X3) off = (((size_t)(n0 + row) * 3 + c4 / (BK / 8)) * p.Cin2 + kc + (c4 % (BK / 8)) * 8) * 2;
+          else off = ((size_t)(n0 + row) * p.Cin2 + kc + c4 * EPB) * WSZ;
+          v = *reinterpret_cast<const float4*>(w2b + off);
+        }
         breg[i] = v;
       }
     };

@@ -38,6 +38,7 @@
 #define RIB_VSK(sec, ...) RIB_I_VSK(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VB(sec, ...) RIB_I_VB(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VBX(sec, ...) RIB_I_VBX(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VX3(sec, ...) RIB_I_VX3(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
 #undef RIB_V
 #undef RIB_VK
@@ -49,6 +50,7 @@
 #undef RIB_VSK
 #undef RIB_VB
 #undef RIB_VBX
+#undef RIB_VX3
 
 using namespace rib;
 
@@ -191,7 +193,7 @@ typedef void (*IgemmFn)(const IgemmParams);
 struct Variant {
   int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
   IgemmFn fn;          // generic instantiation (fused-shortcut loop and input prologue compiled in)
-  bool BF16 = false;   // bf16 matrix-core twin of the same geometry
+  int BF16 = 0;        // precision of this instantiation: PREC_F32 / PREC_BF16 (bf16 storage) / PREC_F32X3 (fp32 storage, split-bf16 operands)
   IgemmFn fn_pro = nullptr;    // without the fused-shortcut loop
   IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int KW = 1;                  // in-workgroup split-K: KW groups of 4 waves (256*KW threads) per tile
@@ -202,7 +204,7 @@ struct Variant {
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
-    const int ck = (BF16 ? BK / 2 : BK) + 4;                                                  // IgemmGeom::CK
+    const int ck = (BF16 == PREC_BF16 ? BK / 2 : (BF16 == PREC_F32X3 ? 3 * BK / 2 : BK)) + 4;   // IgemmGeom::CK
     const int main_loop = ((TB == 9 ? 2 : 1) * ih * iwp * ck + 2 * TB * BN() * ck) * 4;   // IgemmGeom::NA
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
@@ -254,6 +256,9 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW},
 #define RIB_VB(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true},
+#define RIB_VX3(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 2, nullptr, nullptr, KW, TB},
 #define RIB_VBX(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, true, nullptr, nullptr, KW, TB},
@@ -277,16 +282,16 @@ const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 // A split-K launch pays a second (slab-summing) kernel.
 struct Choice { const Variant* v = nullptr; int ksplit = 1; double cycles = 0; };
 
-Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                          int Cin, bool allow_split, int Cin2, bool allow_n16);
 
-Choice choose_variant(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+Choice choose_variant(int bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                       int Cin, bool allow_split, int Cin2 = 0, bool allow_n16 = false) {
   // a bf16 handle stores bf16 activations: only the bf16 kernels can read them
-  return choose_variant_dt(bf16, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16 && !bf16);
+  return choose_variant_dt(bf16, stride, ks, ups, spade, ncols, B, Hout, Wout, Cin, allow_split, Cin2, allow_n16 && bf16 == PREC_F32);
 }
 
-Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
+Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int ncols, int B, int Hout, int Wout,
                          int Cin, bool allow_split, int Cin2, bool allow_n16) {
   Choice best;
   best.cycles = 1e300;
@@ -295,7 +300,7 @@ Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, in
     const Variant& v = kVariants[i];
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     if (v.NF == 0 && !allow_n16) continue;
-    if (v.BF16 != bf16) continue;
+    if (v.BF16 != bf16) continue;   // (bf16 carries the handle's precision mode)
     const int BK = v.BK;
     // in-workgroup split-K only where the tile grid alone cannot fill the chip
     if ((v.KW > 1 || v.TB > 1) && (long)((Hout + v.TH() - 1) / v.TH()) * ((Wout + v.TW() - 1) / v.TW()) * ((ncols + v.BN() - 1) / v.BN()) * B >= 512) continue;
@@ -311,7 +316,7 @@ Choice choose_variant_dt(bool bf16, int stride, int ks, bool ups, bool spade, in
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ups ? 16 : ks * ks;
       const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0
-                                        : (v.BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
+                                        : (v.BF16 == PREC_BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (v.BF16 == PREC_F32X3 ? (BK / 16) * v.MF * v.NF * 6 * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0));
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
       // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
@@ -437,9 +442,12 @@ struct rib_handle {
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
   bool weights_ready = false;
-  bool compute_bf16 = false;   // rib_set_compute_dtype
-  int padc(int c) const { return compute_bf16 ? pad16(c) : pad8(c); }   // channel padding of an activation
-  int esz() const { return compute_bf16 ? 2 : 4; }                       // bytes per stored activation / filter element
+  bool compute_bf16 = false;   // rib_set_compute_dtype: bf16 storage + bf16 matrix cores
+  bool compute_x3 = false;     //                         fp32 storage, split-bf16 (hi + mid + lo) matrix-core operands
+  int prec() const { return compute_bf16 ? PREC_BF16 : (compute_x3 ? PREC_F32X3 : PREC_F32); }
+  bool mc16() const { return compute_bf16 || compute_x3; }               // the matrix-core kernels read bf16 filter copies, 16-channel steps
+  int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
+  int esz() const { return compute_bf16 ? 2 : 4; }                       // bytes per stored activation element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
@@ -512,13 +520,14 @@ void assign_weight_layout(rib_handle* h) {
     h->spade_index[sg.key] = (int)h->spades.size();
     h->spades.push_back(sg);
   }
-  if (h->compute_bf16) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float)
+  if (h->mc16()) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float); f32x3: three planes
+    const size_t pl = h->compute_x3 ? 3 : 1;
     for (auto& c : h->convs) {
       if (!c.used) continue;
-      c.w16_off = take(((size_t)c.coutp * c.ks * c.ks * c.cinp + 1) / 2);
-      if (c.ups_in) c.wp16_off = take(((size_t)c.coutp * 16 * c.cinp + 1) / 2);
+      c.w16_off = take((pl * c.coutp * c.ks * c.ks * c.cinp + 1) / 2);
+      if (c.ups_in) c.wp16_off = take((pl * c.coutp * 16 * c.cinp + 1) / 2);
     }
-    for (auto& sg : h->spades) sg.w16_off = take(((size_t)sg.npad * h->padc(sg.cond) + 1) / 2);
+    for (auto& sg : h->spades) sg.w16_off = take((pl * sg.npad * h->padc(sg.cond) + 1) / 2);
   }
   h->blob_floats = off;
 }
@@ -664,14 +673,14 @@ struct Builder {
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
     // the 16-column path serves layers with <= 16 output channels and no residual read
-    const bool can_n16 = c.cout <= 16 && !a.res && !h->compute_bf16 && !getenv("RIB_NO_N16");
-    Choice ch = choose_variant(h->compute_bf16, c.stride, c.ks, a.ups, false, c.coutp, TB_(), Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
+    const bool can_n16 = c.cout <= 16 && !a.res && !h->mc16() && !getenv("RIB_NO_N16");
+    Choice ch = choose_variant(h->prec(), c.stride, c.ks, a.ups, false, c.coutp, TB_(), Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        const bool ok = tv.BF16 == h->compute_bf16 && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+        const bool ok = tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
                         (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
@@ -711,13 +720,13 @@ struct Builder {
       }
     }
     // matrix-core kernels of a bf16 handle read the bf16 filter copies; the direct head convolutions keep fp32 filters
-    const bool w16 = h->compute_bf16 && !small;
+    const bool w16 = h->mc16() && !small;
     op.w = WT(a.ups ? (w16 ? c.wp16_off : c.wp_off) : (w16 ? c.w16_off : c.w_off)); op.bias = WT(c.b_off);
     double aux_flops = 0.0;
     if (a.aux) {
       if (c.ks != 3 || c.stride != 1 || a.ups || !c.fb_off || a.aux->ks != 1 || a.aux->coutp != c.coutp || a.aux_in.Cp != a.aux->cinp ||
           a.aux_in.H != Hout || a.aux_in.W != Wout) { error = opname + ": fused shortcut operand does not fit"; return false; }
-      op.x2 = WS(a.aux_in.off); op.w2 = WT(h->compute_bf16 ? a.aux->w16_off : a.aux->w_off); op.bias = WT(c.fb_off);
+      op.x2 = WS(a.aux_in.off); op.w2 = WT(h->mc16() ? a.aux->w16_off : a.aux->w_off); op.bias = WT(c.fb_off);
       p.x2C = a.aux_in.Cp; p.Cin2 = a.aux->cinp;
       aux_flops = 2.0 * a.aux->cin * a.aux->cout * (double)Hout * Wout * B;
     }
@@ -795,17 +804,17 @@ struct Builder {
     // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
     // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
     // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
-    const Variant* v = choose_variant(h->compute_bf16, 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    const Variant* v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
     Choice uf;   // unfused candidate
     const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
-    if (small_map) uf = choose_variant(h->compute_bf16, 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
+    if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
     bool unfused = small_map && uf.v != nullptr;
     {
       auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        if (tv.BF16 != h->compute_bf16 || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
+        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
           error = key + ": tuned SPADE choice does not fit"; return false;
         }
         if (tv.SPADE) { v = &tv; unfused = false; }
@@ -825,7 +834,7 @@ struct Builder {
       p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
       p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
       p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
-      op.x = WS(cond.off); op.w = WT(h->compute_bf16 ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
+      op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
       op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
       op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
       P->flops[RIB_KC_SPADE] += op.flops;
@@ -853,7 +862,7 @@ struct Builder {
     p.ksplit = 1;
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
-    op.x = WS(cond.off); op.w = WT(h->compute_bf16 ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off);
+    op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off);
     op.xm = WS(x.off);
     if (has_partials(nx) && !nx.pend->affine && sg.Cp <= nx.pend->Cs) {   // consumer-side finalize in the SPADE epilogue
       const PendingStats& ps = *nx.pend;
@@ -1573,17 +1582,28 @@ int rib_finalize_weights(rib_handle* h) {
       }
     }
   }
-  if (h->compute_bf16) {
-    auto to16 = [&](size_t src, size_t dst, size_t n) {
+  if (h->mc16()) {
+    // rows of `rowlen` K-contiguous elements: bf16 -> [row][rowlen]; f32x3 -> [row][plane][rowlen] with
+    // hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (exact subtractions), as the kernels split activations
+    const bool x3 = h->compute_x3;
+    auto bf = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto to16 = [&](size_t src, size_t dst, size_t rows, size_t rowlen) {
       uint16_t* d = reinterpret_cast<uint16_t*>(&blob[dst]);
-      for (size_t i = 0; i < n; ++i) d[i] = host_bf16(blob[src + i]);
+      for (size_t r = 0; r < rows; ++r)
+        for (size_t i = 0; i < rowlen; ++i) {
+          const float w = blob[src + r * rowlen + i];
+          if (!x3) { d[r * rowlen + i] = host_bf16(w); continue; }
+          const uint16_t hb = host_bf16(w); const float r1 = w - bf(hb);
+          const uint16_t mb = host_bf16(r1); const float r2 = r1 - bf(mb);
+          d[(r * 3 + 0) * rowlen + i] = hb; d[(r * 3 + 1) * rowlen + i] = mb; d[(r * 3 + 2) * rowlen + i] = host_bf16(r2);
+        }
     };
     for (auto& c : h->convs) {
       if (!c.used) continue;
-      to16(c.w_off, c.w16_off, (size_t)c.coutp * c.ks * c.ks * c.cinp);
-      if (c.ups_in) to16(c.wp_off, c.wp16_off, (size_t)c.coutp * 16 * c.cinp);
+      to16(c.w_off, c.w16_off, (size_t)c.coutp * c.ks * c.ks, c.cinp);      // a "row" is one (output channel, tap) slice
+      if (c.ups_in) to16(c.wp_off, c.wp16_off, (size_t)c.coutp * 16, c.cinp);
     }
-    for (auto& sg : h->spades) to16(sg.w_off, sg.w16_off, (size_t)sg.npad * h->padc(sg.cond));
+    for (auto& sg : h->spades) to16(sg.w_off, sg.w16_off, sg.npad, h->padc(sg.cond));
   }
   if (h->device < 0) {
     h->host_blob.swap(blob);
@@ -1631,14 +1651,15 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
 }
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
-  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
-  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16)) return RIB_OK;
+  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16 && dtype != RIB_DTYPE_F32X3)) return RIB_ERR_INVALID;
+  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16) && h->compute_x3 == (dtype == RIB_DTYPE_F32X3)) return RIB_OK;
   // The storage type decides the activation / filter layout (bf16: 16-channel minimum, bf16 filter copies in the
   // blob): plans and the weight layout are rebuilt, and the folded blob has to be produced again - by
   // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
   // exported by a handle of the same storage type.
   h->plans.clear();
   h->compute_bf16 = dtype == RIB_DTYPE_BF16;
+  h->compute_x3 = dtype == RIB_DTYPE_F32X3;
   assign_weight_layout(h);
   const bool had = h->weights_ready || !h->host_blob.empty();
   h->weights_ready = false;
@@ -1968,7 +1989,7 @@ int rib_variant_info(int idx, int geom[12]) {
   const Variant& v = kVariants[idx];
   const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.TB};
   for (int i = 0; i < 12; ++i) geom[i] = g[i];
-  return v.BF16 ? 1 : RIB_OK;   // 1: the bf16 matrix-core twin of that geometry
+  return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage, 2 f32x3
 }
 
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit) {

@@ -6,7 +6,7 @@
 // rib.hip's RIB_V / RIB_VK / ... table macros name the same instantiations; keep the two in step.
 #pragma once
 
-// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, BF16, AUX, PRO, KW, TB
+// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (false / true = 0 / 1), AUX, PRO, KW, TB
 #define RIB_F_EXTERN(...) extern template __global__ void rib::k_igemm<__VA_ARGS__>(const rib::IgemmParams);
 #define RIB_F_TOUCH(...) &rib::k_igemm<__VA_ARGS__>,
 
@@ -45,3 +45,6 @@
 // bf16-storage variant with explicit wave groups / slices per barrier (one instantiation: shortcut loop where it can exist, prologue)
 #define RIB_I_VBX(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
   F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
+// f32x3 variant (fp32 storage, operands split into three bf16 terms): PREC = 2
+#define RIB_I_VX3(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)

@@ -8,13 +8,17 @@ import ctypes as C
 import json
 import os
 
-TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
-TUNING_PATH_BF16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950_bf16.json")   # measured on the bf16-storage kernels
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TUNING_PATH = os.path.join(_HERE, "tuning_gfx950.json")
+# one table per precision mode, each measured on that mode's own kernels (tools/autotune.py --dtype ...)
+TUNING_PATHS = {"f32": TUNING_PATH, "bf16": os.path.join(_HERE, "tuning_gfx950_bf16.json"),
+                "f32x3": os.path.join(_HERE, "tuning_gfx950_f32x3.json")}
+PREC = {"f32": 0, "bf16": 1, "f32x3": 2}           # what rib_variant_info returns for a variant of that mode
 
 
-def load(path=None, bf16=False):
+def load(path=None, dtype="f32"):
     if path is None:
-        path = TUNING_PATH_BF16 if bf16 else TUNING_PATH
+        path = TUNING_PATHS[dtype]
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
@@ -27,17 +31,16 @@ def save(table, path=TUNING_PATH):
         json.dump(table, f, indent=0, sort_keys=True)
 
 
-def apply(lib, handle, table, B, H, W, bf16=False):
-    """Pin the tuned choices of shape (B,H,W) on a handle; returns how many were applied.  The table
-    is measured in fp32; a bf16 handle takes the bf16 twin of each tuned geometry where one exists."""
+def apply(lib, handle, table, B, H, W, dtype="f32"):
+    """Pin the tuned choices of shape (B,H,W) on a handle; returns how many were applied.  Only variants of the
+    handle's precision mode are eligible; an entry whose geometry no longer exists is skipped (model choice)."""
     entry = table.get("%d,%d,%d" % (B, H, W))
     if not entry:
         return 0
     g11 = (C.c_int * 12)()
     geoms = {}
     for i in range(lib.rib_num_variants()):
-        is_bf16 = lib.rib_variant_info(i, g11) == 1
-        if is_bf16 == bool(bf16) or (bf16 and tuple(g11) not in geoms):
+        if lib.rib_variant_info(i, g11) == PREC[dtype]:
             geoms[tuple(g11)] = i
     n = 0
     for op, choice in entry.items():
@@ -46,8 +49,6 @@ def apply(lib, handle, table, B, H, W, bf16=False):
         kwg = int(choice[11]) if len(choice) > 11 else 1
         tb = int(choice[12]) if len(choice) > 12 else 1
         idx = geoms.get(tuple(choice[:10]) + (kwg, tb))
-        if idx is None and bf16:
-            idx = geoms.get(tuple(choice[:10]) + (1, 1))
         if idx is None:
             continue                      # variant table changed since tuning: model choice
         if lib.rib_set_choice(handle, B, H, W, op.encode(), idx, int(choice[10])) == 0:

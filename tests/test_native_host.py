@@ -193,7 +193,7 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
     g12 = (C.c_int * 12)()
     geoms = set()
     for i in range(lib.rib_num_variants()):
-        if lib.rib_variant_info(i, g12) == 0:            # fp32 variants (the table is measured in fp32)
+        if lib.rib_variant_info(i, g12) == 0:            # fp32 variants (this table is measured in fp32)
             geoms.add(tuple(g12))
     table = tuning.load()
     assert "1,512,512" in table and len(table["1,512,512"]) >= 60

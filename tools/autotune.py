@@ -26,14 +26,14 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="storage / matrix-core type whose kernels are measured")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32", help="precision mode whose kernels are measured")
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--report", type=str, default=None)
     ap.add_argument("--only", type=str, default=None,
                     help="re-tune only the launches whose name contains this substring; other entries of the shape are kept")
     args = ap.parse_args()
     if args.out is None:
-        args.out = tuning.TUNING_PATH_BF16 if args.dtype == "bf16" else tuning.TUNING_PATH
+        args.out = tuning.TUNING_PATHS[args.dtype]
     lib = _native.lib()
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
@@ -44,8 +44,8 @@ def main():
     geoms = []
     g10 = (C.c_int * 12)()
     for i in range(nvar):
-        is_bf16 = lib.rib_variant_info(i, g10) == 1
-        geoms.append(list(g10) if is_bf16 == (args.dtype == "bf16") else None)      # only the kernels of this storage type
+        prec = lib.rib_variant_info(i, g10)
+        geoms.append(list(g10) if prec == tuning.PREC[args.dtype] else None)      # only the kernels of this precision mode
     table = tuning.load(args.out)
     report = []
     for size in args.size:

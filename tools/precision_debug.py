@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug aid for the bf16 storage mode: per-tap max-abs error vs the fp32 CPU oracle (in plan order), then the
+"""Debug aid for the bf16 / f32x3 precision modes (argv[1]): per-tap error vs the fp32 CPU oracle (in plan order), then the
 frame error at a few sizes.  Run on the GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ MID = dict(num_filters=16, max_num_filters=64, mask=dict(num_filters=32, max_num
 for name, cfg, sizes in (("mid", rib.hsm_gen_config(**MID), [(1, 64, 64)]), ("full", rib.hsm_gen_config(), [(1, 64, 64), (2, 48, 80), (1, 256, 256)])):
     spec = rib.GenSpec.from_cfg(cfg)
     sd = synth.make_state_dict(spec, 7)
-    G = rib.Generator(cfg, compute_dtype="bf16").eval()
+    G = rib.Generator(cfg, compute_dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16")).eval()
     G.load_state_dict(sd)
     R = generator_ref.RefGenerator(spec, sd)
     for (B, H, W) in sizes:
