@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librib.so")
+# RIB_LIBRARY: another build of the same C ABI (A/B measurements of two builds inside one gpurun call)
+LIB_PATH = os.environ.get("RIB_LIBRARY") or os.path.join(_HERE, "csrc", "librib.so")
 
 KC_NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
 

@@ -123,7 +123,7 @@ struct IgemmParams {
   const float* res;      // residual added before act/store, [B][Hout][Wout][resC] or nullptr
   int resC, res_ups;     // res_ups: residual stored at half resolution (nearest x2 upsample on read)
   float* y_nchw;         // optional second copy of the output as [B][Cout][Hout][Wout]
-  float* stat_part;      // optional per-tile partial sums [B][tiles][2][CoutPad]
+  double* stat_part;     // optional per-tile partial sums [B][tiles][2][CoutPad], fp64 from the first add on
   // (the bf16 matrix-core mode, v_mfma_f32_32x32x16_bf16 on the same fp32 LDS tiles with fp32
   // accumulate / statistics / storage, is the BF16 template flag: a runtime switch inside the tap
   // loop cost the fp32 kernels 8 % through register pressure)
@@ -142,32 +142,34 @@ struct IgemmParams {
   // --- consumer-side InstanceNorm finalize ---
   // When the producer of a normalised tensor left few per-tile partial sums (<= STATS_MAX_PARTIALS), the consumer
   // reduces them itself instead of reading (scale, shift) arrays written by a k_stats_finalize launch: one dependent
-  // launch (~5 us on a 3 ms frame, 44 of them) less per normalised tensor.  part = [B][tiles][2][Cs] fp32.
-  const float* pro_part; int pro_tiles, pro_Cs; float pro_inv;   // prologue: replaces pro_scale / pro_shift
+  // launch less per normalised tensor.  part = [B][tiles][2][Cs] fp64: the producers' epilogues accumulate sum(x)
+  // and sum(x^2) in fp64 from the element level, so E[x^2] - mean^2 does not cancel when |mean| >> std (an fp32
+  // partial of x^2 loses the variance once mean^2 / var reaches ~1e6; torch's instance_norm does not).
+  const double* pro_part; int pro_tiles, pro_Cs; float pro_inv;  // prologue: replaces pro_scale / pro_shift
   const float* pro_gamma; const float* pro_beta;                 //   IN affine of the producer (mask network), or nullptr
-  const float* m_part; int m_tiles, m_Cs; float m_inv;           // SPADE epilogue: replaces m_scale / m_shift (no affine)
+  const double* m_part; int m_tiles, m_Cs; float m_inv;          // SPADE epilogue: replaces m_scale / m_shift (no affine)
 };
 
 enum { STATS_MAX_PARTIALS = 128, STATS_MAX_PRO_CH = 512 };
 
 // (scale, shift) of ONE channel from the per-tile partial sums of its producer; `base` points at the sample's
-// [tiles][2][Cs] block.  Same arithmetic as k_stats_finalize (fp64 sums of the fp32 partials in tile order,
-// biased variance, eps 1e-5), so the two paths agree to the last bit whenever the tile order of the sum is the same.
-__device__ __forceinline__ void stats_from_partials(const float* base, int tiles, int Cs, int c, int t0, int tstep,
+// [tiles][2][Cs] block.  Same arithmetic as k_stats_finalize (fp64 sums in a fixed tile order, biased variance,
+// eps 1e-5), so the two paths agree to the last bit whenever the tile order of the sum is the same.
+__device__ __forceinline__ void stats_from_partials(const double* base, int tiles, int Cs, int c, int t0, int tstep,
                                                     double& a1, double& a2) {
   a1 = 0.0; a2 = 0.0;
   int t = t0;
   for (; t + 3 * tstep < tiles; t += 4 * tstep) {   // 8 independent loads in flight
-    const float x0 = base[(size_t)t * 2 * Cs + c], y0 = base[(size_t)t * 2 * Cs + Cs + c];
-    const float x1 = base[(size_t)(t + tstep) * 2 * Cs + c], y1 = base[(size_t)(t + tstep) * 2 * Cs + Cs + c];
-    const float x2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + c], y2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + Cs + c];
-    const float x3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + c], y3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + Cs + c];
-    a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
-    a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+    const double x0 = base[(size_t)t * 2 * Cs + c], y0 = base[(size_t)t * 2 * Cs + Cs + c];
+    const double x1 = base[(size_t)(t + tstep) * 2 * Cs + c], y1 = base[(size_t)(t + tstep) * 2 * Cs + Cs + c];
+    const double x2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + c], y2 = base[(size_t)(t + 2 * tstep) * 2 * Cs + Cs + c];
+    const double x3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + c], y3 = base[(size_t)(t + 3 * tstep) * 2 * Cs + Cs + c];
+    a1 += (x0 + x1) + (x2 + x3);
+    a2 += (y0 + y1) + (y2 + y3);
   }
   for (; t < tiles; t += tstep) {
-    a1 += (double)base[(size_t)t * 2 * Cs + c];
-    a2 += (double)base[(size_t)t * 2 * Cs + Cs + c];
+    a1 += base[(size_t)t * 2 * Cs + c];
+    a2 += base[(size_t)t * 2 * Cs + Cs + c];
   }
 }
 __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_count, float g, float b, float& sc, float& sh) {
@@ -218,7 +220,7 @@ struct IgemmGeom {
   static constexpr int SA = IH * IWP * CK;     // floats
   static constexpr int SB = BN * CK;           // floats, one of two buffers
   static constexpr int NB4 = (BN * GPRB + NT - 1) / NT;    // 16-byte filter loads per thread per tap
-  static constexpr int SRED = WM * BN * 2;
+  static constexpr int SRED = WM * BN * 4;     // floats: [WM][BN][2] fp64 statistics partials
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   static constexpr int NA = TB == 9 ? 2 : 1;   // TB = 9 also double-buffers the input tile: one barrier per chunk
   static constexpr int SMEM0 = NA * SA + 2 * TB * SB > SRED ? NA * SA + 2 * TB * SB : SRED;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   auto consumer_stats = [&]() {
     if constexpr (PRO && !SPADE) {
       if (p.pro_part) {
-        const float* base = p.pro_part + (size_t)n * p.pro_tiles * 2 * p.pro_Cs;
+        const double* base = p.pro_part + (size_t)n * p.pro_tiles * 2 * p.pro_Cs;
         for (int c = tid; c < p.Cin; c += NT) {     // input channel c of x is channel c of its producer
           double a1, a2;
           stats_from_partials(base, p.pro_tiles, p.pro_Cs, c, 0, 1, a1, a2);
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     const int col = n0 + l15;
     const bool cvalid = col < p.Cout;
     const float bv = p.bias[min(col, p.CoutPad - 1)];
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -887,22 +889,22 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
             const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
             p.y[pix * p.yC + p.yoff + col] = v;
             if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = v;
-            s1 += v;
-            s2 += v * v;
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
           }
         }
     if (p.stat_part) {
       __syncthreads();
-      float* red = smem;   // [WM][16][2]
-      float a1 = s1 + __shfl_xor(s1, 16); a1 += __shfl_xor(a1, 32);
-      float a2 = s2 + __shfl_xor(s2, 16); a2 += __shfl_xor(a2, 32);
+      double* red = reinterpret_cast<double*>(smem);   // [WM][16][2]
+      double a1 = s1 + __shfl_xor(s1, 16); a1 += __shfl_xor(a1, 32);
+      double a2 = s2 + __shfl_xor(s2, 16); a2 += __shfl_xor(a2, 32);
       if (lane < 16) { red[(wm * 16 + l15) * 2] = a1; red[(wm * 16 + l15) * 2 + 1] = a2; }
       __syncthreads();
       if (tid < 16) {
-        float b1 = 0.f, b2 = 0.f;
+        double b1 = 0.0, b2 = 0.0;
 #pragma unroll
         for (int m = 0; m < WM; ++m) { b1 += red[(m * 16 + tid) * 2]; b2 += red[(m * 16 + tid) * 2 + 1]; }
-        float* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
+        double* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
         dst[n0 + tid] = b1;
         dst[p.CoutPad + n0 + tid] = b2;
       }
@@ -929,9 +931,9 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       }
     }
   } else if (!SPADE) {
-    float s1[NF], s2[NF];
+    double s1[NF], s2[NF];     // fp64 from the first add (see IgemmParams: no fp32 cancellation in E[x^2] - mean^2)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.f; s2[nf] = 0.f; }
+    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.0; s2[nf] = 0.0; }
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int col = n0 + (wn * NF + nf) * 32 + li;
@@ -997,9 +999,22 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }   // phase ph of source pixel (oy, ox)
           const bool ok = cvalid && oy < p.Hout && ox < p.Wout;
           okm |= ok ? (1u << r) : 0u;
-          const float v = ok ? vv[r] : 0.f;      // adding 0 leaves the partial sums unchanged
-          s1[nf] += v;
-          s2[nf] += v * v;
+        }
+        {
+          // sum(x), sum(x^2) of the fragment's valid elements, free of cancellation at fp32 cost: deviations from a
+          // pivot (the lane's first value) are summed in fp32 - they are of the size of the spread, not of the mean -
+          // and the pivot is put back once per fragment in fp64:  sum x = k*p + sum d,  sum x^2 = k*p^2 + 2p*sum d + sum d^2
+          const float pv = vv[0];
+          float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = (okm & (1u << r)) ? vv[r] - pv : 0.f;
+            d1 += d;
+            d2 += d * d;
+          }
+          const double k = (double)__popc(okm), pd = (double)pv;
+          s1[nf] += k * pd + (double)d1;
+          s2[nf] += (k * pd + 2.0 * (double)d1) * pd + (double)d2;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1027,11 +1042,11 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     }
     if (p.stat_part) {   // deterministic per-tile partial sums for the following InstanceNorm
       __syncthreads();   // all waves finished the main loop: smem can be reused
-      float* red = smem;   // [WM][BN][2]
+      double* red = reinterpret_cast<double*>(smem);   // [WM][BN][2]
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        float a1 = s1[nf] + __shfl_xor(s1[nf], 32);
-        float a2 = s2[nf] + __shfl_xor(s2[nf], 32);
+        const double a1 = s1[nf] + __shfl_xor(s1[nf], 32);
+        const double a2 = s2[nf] + __shfl_xor(s2[nf], 32);
         if (lh == 0) {
           const int c = (wn * NF + nf) * 32 + li;
           red[(wm * G::BN + c) * 2 + 0] = a1;
@@ -1040,12 +1055,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       }
       __syncthreads();
       for (int c = tid; c < G::BN; c += 256) {
-        float a1 = 0.f, a2 = 0.f;
+        double a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int m = 0; m < WM; ++m) { a1 += red[(m * G::BN + c) * 2]; a2 += red[(m * G::BN + c) * 2 + 1]; }
         const int col = n0 + c;
         if (col < p.CoutPad) {
-          float* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
+          double* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
           dst[col] = a1;
           dst[p.CoutPad + col] = a2;
         }
@@ -1106,11 +1121,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
 // k_stats_finalize: per-tile partial sums -> (scale, shift) of the InstanceNorm that follows.
 //   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
 //   scale = rstd*gamma, shift = beta - mean*scale   (gamma=1, beta=0 when affine is absent)
-// Tiles are summed in a fixed order in fp64: deterministic and free of fp32 cancellation.
+// The partials are fp64 sums made by the producers' epilogues (fp64 from the first add) and are summed here in a fixed
+// order in fp64: deterministic, and E[x^2] - mean^2 keeps the variance for |mean| / std up to ~1e6.
 // grid (Cs/16, B), block 1024 = 16 channels x 64 tile slices.
 // ---------------------------------------------------------------------------------------------
 struct FinalizeParams {
-  const float* part;   // [B][tiles][2][Cs]
+  const double* part;  // [B][tiles][2][Cs]
   int tiles, Cs, C;    // C valid channels
   const float* gamma;  // [C] or nullptr
   const float* beta;
@@ -1128,22 +1144,7 @@ __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p)
   const int c = blockIdx.x * 16 + cl;
   const int n = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
-  if (c < p.Cs) {
-    const float* base = p.part + (size_t)n * p.tiles * 2 * p.Cs;
-    int t = sl;
-    for (; t + 192 < p.tiles; t += 256) {   // 4 independent loads in flight per accumulator
-      const float x0 = base[(size_t)t * 2 * p.Cs + c], y0 = base[(size_t)t * 2 * p.Cs + p.Cs + c];
-      const float x1 = base[(size_t)(t + 64) * 2 * p.Cs + c], y1 = base[(size_t)(t + 64) * 2 * p.Cs + p.Cs + c];
-      const float x2 = base[(size_t)(t + 128) * 2 * p.Cs + c], y2 = base[(size_t)(t + 128) * 2 * p.Cs + p.Cs + c];
-      const float x3 = base[(size_t)(t + 192) * 2 * p.Cs + c], y3 = base[(size_t)(t + 192) * 2 * p.Cs + p.Cs + c];
-      a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
-      a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
-    }
-    for (; t < p.tiles; t += 64) {
-      a1 += (double)base[(size_t)t * 2 * p.Cs + c];
-      a2 += (double)base[(size_t)t * 2 * p.Cs + p.Cs + c];
-    }
-  }
+  if (c < p.Cs) stats_from_partials(p.part + (size_t)n * p.tiles * 2 * p.Cs, p.tiles, p.Cs, c, sl, 64, a1, a2);
   // fixed-shape reduction over the 64 slices: the 4 slices of a wavefront with shuffles, then the 16
   // wavefront sums in order by one thread per channel (one barrier; an LDS tree needed seven)
   a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
@@ -1181,13 +1182,13 @@ struct SplitEpiParams {
   float* y; int yC, yoff, Cout;
   int act;
   const float* res; int resC, res_ups;
-  float* stat_part; int blocks;
+  double* stat_part; int blocks;
   int Hout, Wout;
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p) {
-  __shared__ __attribute__((aligned(16))) float red[2][256][4];
+  __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.CoutPad / 4;
   const int slots = 256 / c4n;
   const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
   const int ppb = slots * 4;
   const size_t sstride = (size_t)p.B * npix * p.CoutPad;
   const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   // all slab reads of the block's four pixel rounds are issued before the first add: one memory round trip
   // for split factors <= 4 (a load -> add loop per pixel paid one per pixel and per four slabs); the slabs are
   // still added in the fixed order 0, 1, 2, ...
@@ -1260,8 +1261,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       if constexpr (BF16) t = bf16_round(t);      // statistics of the tensor as it is stored
       vals[k][e] = (pix < npix && c4 * 4 + e < p.Cout) ? t : 0.f;
     }
-    s1.x += vals[k][0]; s1.y += vals[k][1]; s1.z += vals[k][2]; s1.w += vals[k][3];
-    s2.x += vals[k][0] * vals[k][0]; s2.y += vals[k][1] * vals[k][1]; s2.z += vals[k][2] * vals[k][2]; s2.w += vals[k][3] * vals[k][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] += (double)vals[k][e]; s2[e] += (double)vals[k][e] * (double)vals[k][e]; }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1274,14 +1275,14 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
     }
   }
   if (p.stat_part) {
-    *reinterpret_cast<float4*>(&red[0][threadIdx.x][0]) = s1;
-    *reinterpret_cast<float4*>(&red[1][threadIdx.x][0]) = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
     __syncthreads();
     for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
       const int g = c / 4, e = c % 4;
-      float a1 = 0.f, a2 = 0.f;
+      double a1 = 0.0, a2 = 0.0;
       for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
-      float* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
+      double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
       dst[c] = a1;
       dst[p.CoutPad + c] = a2;
     }
@@ -1356,13 +1357,13 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
 struct PoolParams {
   const float* x; float* y;
   int H, W, C;          // input size; output H/2 x W/2
-  float* stat_part;     // [B][blocks][2][C]
+  double* stat_part;    // [B][blocks][2][C]
   int blocks;
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
-  __shared__ __attribute__((aligned(16))) float red[2][256][4];
+  __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.C / 4;
   const int slots = 256 / c4n;
   const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
@@ -1370,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
   const int n = blockIdx.y;
   const int npix = Ho * Wo;
   const int ppb = slots * 4;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   const size_t xn = (size_t)n * p.H * p.W * p.C;
   for (int k = 0; k < 4; ++k) {
     const int pix = blockIdx.x * ppb + k * slots + slot;
@@ -1394,19 +1395,20 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
       a.x *= inv9; a.y *= inv9; a.z *= inv9; a.w *= inv9;
       if constexpr (BF16) a = make_float4(bf16_round(a.x), bf16_round(a.y), bf16_round(a.z), bf16_round(a.w));
       st_act4<BF16>(p.y, ((size_t)n * npix + pix) * p.C + c4 * 4, a);
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += (double)av[e]; s2[e] += (double)av[e] * (double)av[e]; }
     }
   }
-  *reinterpret_cast<float4*>(&red[0][threadIdx.x][0]) = s1;
-  *reinterpret_cast<float4*>(&red[1][threadIdx.x][0]) = s2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
   __syncthreads();
   // thread t < C sums channel t over the pixel slots (fixed order)
   for (int c = threadIdx.x; c < p.C; c += 256) {
     const int g = c / 4, e = c % 4;
-    float a1 = 0.f, a2 = 0.f;
+    double a1 = 0.0, a2 = 0.0;
     for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
-    float* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.C;
+    double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.C;
     dst[c] = a1;
     dst[p.C + c] = a2;
   }

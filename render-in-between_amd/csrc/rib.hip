@@ -755,7 +755,7 @@ struct Builder {
     op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B + aux_flops;
     P->flops[RIB_KC_IGEMM] += op.flops;
     if (S == 1) {
-      if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(float)); op.stat = WS(part_off); }
+      if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(double)); op.stat = WS(part_off); }
       push(op);
     } else {
       // split-K: the conv writes raw partial slabs; a second kernel sums them and runs the epilogue
@@ -769,7 +769,7 @@ struct Builder {
       const int blocks = (Hout * Wout + ppb - 1) / ppb;
       e.sp.blocks = blocks;
       e.s_slab = WS(slab_off); e.s_bias = op.bias; e.s_y = op.y; e.s_res = op.res;
-      if (a.want_stats) { part_off = alloc((size_t)B * blocks * 2 * c.coutp * sizeof(float)); e.s_stat = WS(part_off); }
+      if (a.want_stats) { part_off = alloc((size_t)B * blocks * 2 * c.coutp * sizeof(double)); e.s_stat = WS(part_off); }
       e.grid = dim3(blocks, B, 1);
       tiles = blocks;   // the statistics partials now come from the epilogue kernel's blocks
       op.y = PRef(); op.res = PRef();
@@ -1145,7 +1145,7 @@ struct Builder {
         Norm np = norm(pooled.Cp);
         const int slots = 256 / (out.Cp / 4), ppb = slots * 4;
         const int blocks = (pooled.H * pooled.W + ppb - 1) / ppb;
-        const size_t part = alloc((size_t)B * blocks * 2 * out.Cp * sizeof(float));
+        const size_t part = alloc((size_t)B * blocks * 2 * out.Cp * sizeof(double));
         Op op; op.kind = OP_POOL; op.kclass = RIB_KC_POOL; op.name = "down_" + std::to_string(i) + ".pool";
         memset(&op.pp, 0, sizeof op.pp);
         op.pp.H = out.H; op.pp.W = out.W; op.pp.C = out.Cp; op.pp.blocks = blocks;
@@ -1314,12 +1314,12 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x = R.get<const float>(op.x); p.pro_scale = R.get<const float>(op.pro_scale); p.pro_shift = R.get<const float>(op.pro_shift);
         p.w = R.get<const float>(op.w); p.bias = R.get<const float>(op.bias);
         p.y = R.get<float>(op.y); p.res = R.get<const float>(op.res); p.y_nchw = R.get<float>(op.y_nchw);
-        p.stat_part = R.get<float>(op.stat); p.slab = R.get<float>(op.slab);
+        p.stat_part = R.get<double>(op.stat); p.slab = R.get<float>(op.slab);
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
-        p.pro_part = R.get<const float>(op.pro_part); p.pro_gamma = R.get<const float>(op.pro_gamma); p.pro_beta = R.get<const float>(op.pro_beta);
-        p.m_part = R.get<const float>(op.m_part);
+        p.pro_part = R.get<const double>(op.pro_part); p.pro_gamma = R.get<const float>(op.pro_gamma); p.pro_beta = R.get<const float>(op.pro_beta);
+        p.m_part = R.get<const double>(op.m_part);
         if (op.small_co > 0) {
           const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
           if (bf16) switch (op.small_co) {
@@ -1338,7 +1338,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
       } break;
       case OP_FINALIZE: {
         FinalizeParams p = op.fp;
-        p.part = R.get<const float>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
+        p.part = R.get<const double>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
         p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
         hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(1024), 0, st, p);
       } break;
@@ -1353,13 +1353,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
       case OP_SPLITEPI: {
         SplitEpiParams p = op.sp;
         p.slab = R.get<const float>(op.s_slab); p.bias = R.get<const float>(op.s_bias); p.y = R.get<float>(op.s_y);
-        p.res = R.get<const float>(op.s_res); p.stat_part = R.get<float>(op.s_stat);
+        p.res = R.get<const float>(op.s_res); p.stat_part = R.get<double>(op.s_stat);
         if (bf16) hipLaunchKernelGGL(k_splitk_epilogue<true>, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_splitk_epilogue<false>, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_POOL: {
         PoolParams p = op.pp;
-        p.x = R.get<const float>(op.p_x); p.y = R.get<float>(op.p_y); p.stat_part = R.get<float>(op.p_stat);
+        p.x = R.get<const float>(op.p_x); p.y = R.get<float>(op.p_y); p.stat_part = R.get<double>(op.p_stat);
         if (bf16) hipLaunchKernelGGL(k_avgpool<true>, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_avgpool<false>, op.grid, dim3(256), 0, st, p);
       } break;

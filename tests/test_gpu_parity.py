@@ -316,6 +316,25 @@ def test_bf16_storage_mode_error_is_bounded():
     assert float((i32.cpu() - oimg).abs().max()) <= TOL
 
 
+def test_instance_norm_statistics_survive_a_large_channel_mean():
+    """|mean| >> std in a normalised tensor: down_first gets a bias of +100 on every channel, so the tensor the first
+    SPADE normalises has mean ~100 and std ~1 (mean^2 / var ~ 1e4).  The producers accumulate sum(x), sum(x^2) in fp64
+    from the element level, so E[x^2] - mean^2 keeps the variance; fp32 per-tile partials used to lose ~1e-3 of it here.
+    (At this offset the fp32 convolution outputs themselves differ by ~1e-5 between any two fp32 implementations, hence
+    the north star's 1e-3 and not the usual 2e-4.)"""
+    spec, sd, _ = build("full", 0)
+    sd2 = dict(sd)
+    sd2["down_first.layers.conv.bias"] = sd["down_first.layers.conv.bias"] + 100.0
+    G = rib.Generator(rib.hsm_gen_config()).eval()
+    G.load_state_dict(sd2)
+    for (H, W) in ((64, 64), (256, 256)):
+        label, fake, prev = synth.make_inputs(spec, 1, H, W, 21)
+        img, mask = G(label, None, fake, prev)
+        oimg, omask = oracle(spec, sd2)(label, None, fake, prev)
+        d = (float((img.cpu() - oimg).abs().max()), float((mask.cpu() - omask).abs().max()))
+        assert d[0] <= NORTH_STAR_TOL and d[1] <= NORTH_STAR_TOL, (H, W, d)
+
+
 def test_f32x3_mode_is_fp32_grade():
     """Exploratory precision mode: fp32 storage, every matrix-core operand split into three bf16 terms (hi + mid + lo =
     24 significant bits), six bf16 MFMAs per 16-channel step.  The dropped cross terms are below 2^-26 of a product, so
