@@ -164,8 +164,7 @@ def main():
             def step(i=0):
                 g, st = lanes[i % len(lanes)]
                 with torch.cuda.stream(st):
-                    img, mask = g(label, None, fake, prev)
-                    return g.blend(img, mask, fake)
+                    return g.forward_blend(label, None, fake, prev)[2]     # forward + blend (the mask head writes the fused frame)
 
     log("weights ready, warming up")
     for i in range(max(args.warmup, len(lanes))):
@@ -318,7 +317,7 @@ def main():
         "config": {"workload": workload + ", seed-defined random-init HSM.yaml generator (spectral-norm vectors power-iterated)",
                    "frames_per_step_per_gpu": frames_per_step,
                    "parallelism": "%s sharded over %d GPU(s), one RCCL weight broadcast, no per-frame collective" % ("clips" if args.mode == "clips" else "frames", world),
-                   "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W) + 1,
+                   "weight_broadcast_ms": t_bcast_ms, "launches_per_step": G.num_launches(B, H, W),
                    "frames_in_flight_per_gpu": len(lanes),
                    "per_rank_frames_per_s": per_rank_fps,
                    "blob_checksum": sums[0], "blob_checksum_equal_on_all_ranks": len(set(sums)) == 1,

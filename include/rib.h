@@ -113,6 +113,12 @@ size_t rib_workspace_bytes(rib_handle* h, int B, int H, int W);
 int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
                 const float* img_prev, float* img, float* mask, void* workspace,
                 size_t workspace_bytes, void* hip_stream);
+/* The same forward with the driver's blend fused in: fuse = img*mask + img_fake*(1-mask), mask broadcast over the
+ * image channels (PGNR/models/evaluator.py:256-258), written by the kernel that computes the mask.  fuse [B,3,H,W]
+ * fp32 NCHW device memory; may be null (then this IS rib_forward). */
+int rib_forward_blend(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
+                      const float* img_prev, float* img, float* mask, float* fuse,
+                      void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ---- autoregressive segment: replaces the inference loop body of
  *      Evaluator.evaluate_from_folder (PGNR/models/evaluator.py:238-262) ----

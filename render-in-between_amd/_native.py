@@ -47,6 +47,8 @@ SIGNATURES = {
     "rib_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rib_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
                     + [C.c_size_t, C.c_void_p]),
+    "rib_forward_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+                          + [C.c_size_t, C.c_void_p]),
     "rib_chain_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rib_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
                   + [C.c_size_t, C.c_void_p]),

@@ -42,6 +42,13 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float4 lo, const float4 hi) {
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
+// fuse = img*m + dain*(1-m) (PGNR/models/evaluator.py:256-258) with torch's roundings: two products, one difference,
+// one sum, nothing contracted into an fma - the stand-alone k_blend and the blend fused into the mask head agree bit
+// for bit with each other and with the reference's expression
+__device__ __forceinline__ float blend1(float img, float m, float dain) {
+  return __fadd_rn(__fmul_rn(img, m), __fmul_rn(dain, __fsub_rn(1.f, m)));
+}
+
 // ---- storage type of the activations / filters: fp32 (default, the reference's arithmetic) or bf16 (BASELINE
 // configs[2]: bf16 NHWC tensors in HBM and bf16 tiles in LDS - half the bytes everywhere - bf16 matrix-core
 // operands, fp32 accumulation, fp32 InstanceNorm statistics of the ROUNDED values, fp32 SPADE arithmetic).
@@ -148,6 +155,9 @@ struct IgemmParams {
   const double* pro_part; int pro_tiles, pro_Cs; float pro_inv;  // prologue: replaces pro_scale / pro_shift
   const float* pro_gamma; const float* pro_beta;                 //   IN affine of the producer (mask network), or nullptr
   const double* m_part; int m_tiles, m_Cs; float m_inv;          // SPADE epilogue: replaces m_scale / m_shift (no affine)
+  // --- driver blend fused into the mask head (k_conv_head<1>): fuse = img*m + dain*(1-m), NCHW fp32 caller tensors
+  // (PGNR/models/evaluator.py:256-258); all three null when the caller did not ask for the fused frame ---
+  const float* bl_img; const float* bl_dain; float* bl_fuse; int bl_C;
 };
 
 enum { STATS_MAX_PARTIALS = 128, STATS_MAX_PRO_CH = 512 };
@@ -1542,6 +1552,138 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_head: the two heads again (conv_img 16 -> 3 + tanh, conv_mask.0 32 -> 1 + sigmoid), on the matrix cores with the
+// TAPS as GEMM columns.  k_conv_small above is LDS-read-bound (nine shifted reads of every staged input value); here
+// every input pixel is read ONCE, straight from global memory in MFMA operand layout, and multiplied by all
+// 9 x CO (tap, output channel) filter columns at once (v_mfma_f32_16x16x4_f32, exact fp32):
+//     P[pixel][tap*CO + co] = sum_c x[pixel][c] * w[co][tap][c]        for the 18 x 18 halo of a 16 x 16 output tile
+//     out[y][x][co]         = bias[co] + sum_tap P[(y + dy, x + dx)][tap*CO + co]
+// P goes through LDS (one plane per column); the nine-term sum is the only LDS traffic.  The filters live in registers
+// (8 values per lane).  Zero padding falls out of zeroing the operand of out-of-image halo pixels (after the prologue).
+// For the mask head the driver's blend is fused: the thread that has the pixel's mask also writes the fused frame.
+// CIN = padded input channels (16 or 32); grid (tiles, 1, B), block 256; IgemmParams as for k_conv_small.
+// ---------------------------------------------------------------------------------------------
+template <int CO, int CIN, bool BF16 = false>
+__global__ __launch_bounds__(256) void k_conv_head(const IgemmParams p) {
+  constexpr int NCOL = 9 * CO, NB = (NCOL + 15) / 16, NG = CIN / 16;
+  constexpr int HW_ = 18, HPX = HW_ * HW_, NBLK = (HPX + 15) / 16, PP = HPX + 1;
+  __shared__ float sP[NCOL * PP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int n = blockIdx.z;
+  const int tile = p.xcd_chunk ? (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ty0 = (tile / p.tilesX) * 16, tx0 = (tile % p.tilesX) * 16;
+  // B operand: lane (k group q, column l15) holds w[co][tap][16 g + 4 q + t] of its column for every (g, t) MFMA step
+  float bw[NG][4][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 16 + l15;
+    const int tap = col / CO, co = col % CO;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < NCOL) w4 = *reinterpret_cast<const float4*>(p.w + ((size_t)co * 9 + tap) * CIN + g * 16 + q * 4);
+      bw[g][0][nb] = w4.x; bw[g][1][nb] = w4.y; bw[g][2][nb] = w4.z; bw[g][3][nb] = w4.w;
+    }
+  }
+  float4 psc[NG], psh[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    psc[g] = make_float4(1.f, 1.f, 1.f, 1.f); psh[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pro_scale) {
+      psc[g] = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + g * 16 + q * 4);
+      psh[g] = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + g * 16 + q * 4);
+    }
+  }
+  const size_t xn = (size_t)n * p.Hin * p.Win * p.xC;
+  // every wave owns NBW 16-pixel blocks of the halo; ALL their operand loads are issued before the first use (clamped,
+  // always valid addresses): one memory round trip per workgroup instead of one per block
+  constexpr int NBW = (NBLK + 3) / 4;
+  float4 areg[NBW][NG];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int px = min((wave + 4 * i) * 16 + l15, HPX - 1);
+    const int cy = min(max(ty0 - 1 + px / HW_, 0), p.Hin - 1), cx = min(max(tx0 - 1 + px % HW_, 0), p.Win - 1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) areg[i][g] = ld_act4<BF16>(p.x, xn + (size_t)(unsigned)((cy * p.Win + cx) * p.xC + g * 16 + q * 4));
+  }
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int blk = wave + 4 * i;
+    if (blk >= NBLK) break;
+    const int px = blk * 16 + l15;                       // halo pixel of this lane's A row
+    const int iy = ty0 - 1 + px / HW_, ix = tx0 - 1 + px % HW_;
+    const bool inb = px < HPX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+    float4 a[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 v = areg[i][g];
+      if (p.pro_scale) v = make_float4(v.x * psc[g].x + psh[g].x, v.y * psc[g].y + psh[g].y, v.z * psc[g].z + psh[g].z, v.w * psc[g].w + psh[g].w);
+      if (p.pro_lrelu) v = lrelu4(v);
+      if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding after the prologue
+      a[g] = v;
+    }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float av = t == 0 ? a[g].x : t == 1 ? a[g].y : t == 2 ? a[g].z : a[g].w;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g][t][nb], acc[nb], 0, 0, 0);
+      }
+    // accumulator element r of lane (q, l15): pixel blk*16 + 4 q + r, column nb*16 + l15
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = nb * 16 + l15;
+      if (col < NCOL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ppx = blk * 16 + q * 4 + r;
+          if (ppx < HPX) sP[col * PP + ppx] = acc[nb][r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = ty0 + ly, ox = tx0 + lx;
+  if (oy >= p.Hout || ox >= p.Wout) return;
+  float o[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) o[co] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int hp = (ly + tap / 3) * HW_ + lx + tap % 3;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) o[co] += sP[(tap * CO + co) * PP + hp];
+  }
+  const size_t pix = ((size_t)n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    const float v = apply_act(o[co] + p.bias[co], p.act);
+    o[co] = v;
+    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v;
+    if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
+  }
+  for (int co = CO; co < p.Cout; ++co) {   // channel padding, as k_igemm stores it
+    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
+  }
+  if constexpr (CO == 1) {
+    if (p.bl_fuse) {                        // evaluator.py:256-258, same operation order as k_blend
+      const float m = o[0];
+      const size_t hw = (size_t)p.Hout * p.Wout, at = (size_t)oy * p.Wout + ox;
+      for (int c = 0; c < p.bl_C; ++c) {
+        const size_t i = ((size_t)n * p.bl_C + c) * hw + at;
+        p.bl_fuse[i] = blend1(p.bl_img[i], m, p.bl_dain[i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_gather6: up to six device-to-device copies in one launch (rib_chain: a frame's slices of the batched
 // label-only results into the frame plan's slots).  Sizes are multiples of 16 bytes; grid (blocks, 6).
 // ---------------------------------------------------------------------------------------------
@@ -1616,7 +1758,7 @@ __global__ __launch_bounds__(256) void k_blend(const float* img, const float* ma
     const size_t pix = i % HW;
     const size_t n = i / ((size_t)C * HW);
     const float m = mask[n * HW + pix];
-    fuse[i] = img[i] * m + dain[i] * (1.f - m);
+    fuse[i] = blend1(img[i], m, dain[i]);
   }
 }
 

@@ -342,7 +342,7 @@ enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
 enum PtrSpace { PS_NULL = 0, PS_WS, PS_WEIGHT, PS_USER };
-enum UserSlot { U_LABEL = 0, U_FAKE, U_PREV, U_IMG, U_MASK, U_COUNT };
+enum UserSlot { U_LABEL = 0, U_FAKE, U_PREV, U_IMG, U_MASK, U_FUSE, U_COUNT };   // U_FUSE: optional fused frame (null: no blend)
 struct PRef {
   PtrSpace sp = PS_NULL;
   size_t off = 0;   // bytes for WS, floats for WEIGHT, slot id for USER
@@ -365,7 +365,10 @@ struct Op {
   const Variant* var = nullptr;
   std::string for_op;        // a finalize launch emitted on behalf of this consumer (rib_time_op times them together)
   bool label_only = false;   // depends on the label map only (pack.label, down_first, the mask network's label branch)
-  int small_co = 0;   // > 0: direct vector-ALU convolution k_conv_small<small_co> instead of the matrix-core kernel
+  int small_co = 0;   // > 0: a head convolution with small_co output channels: k_conv_head (matrix cores, taps as GEMM
+                      //      columns) when `head`, else k_conv_small (direct, vector ALUs), instead of k_igemm
+  bool head = false;
+  bool fuse_blend = false;   // the mask head also writes the driver's blend into user slot U_FUSE when the caller gave one
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
   PRef pro_part, pro_gamma, pro_beta, m_part;   // consumer-side InstanceNorm finalize (IgemmParams)
@@ -741,6 +744,10 @@ struct Builder {
     op.y_nchw = a.y_nchw;
     if (small) {
       op.small_co = c.cout;
+      op.head = c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV");
+      // the mask head has every pixel's mask in a register: the driver's blend (evaluator.py:256-258) rides along
+      op.fuse_blend = op.head && c.cout == 1 && a.y_user.sp == PS_USER && a.y_user.off == (size_t)U_MASK;
+      p.bl_C = h->g.c.image_nc;
       p.ksplit = 1;
       p.tilesX = (Wout + 15) / 16; p.tilesY = (Hout + 15) / 16; p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       op.grid = dim3(p.tilesX * p.tilesY, 1, B);
@@ -1288,6 +1295,15 @@ struct Resolver {
   }
 };
 
+template <int CO, int CIN> void launch_head_t(bool bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
+  if (bf16) hipLaunchKernelGGL((k_conv_head<CO, CIN, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_head<CO, CIN, false>), grid, dim3(256), 0, st, p);
+}
+void launch_head(int co, int cin, bool bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
+  if (cin == 16) { if (co == 1) launch_head_t<1, 16>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 16>(bf16, grid, st, p); else launch_head_t<3, 16>(bf16, grid, st, p); }
+  else { if (co == 1) launch_head_t<1, 32>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 32>(bf16, grid, st, p); else launch_head_t<3, 32>(bf16, grid, st, p); }
+}
+
 int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool single_stream = false, bool skip_label_ops = false) {
   const bool multi = h->use_streams && !single_stream && h->side[ST_EMBED] != nullptr;
   if (multi)
@@ -1320,7 +1336,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
         p.pro_part = R.get<const double>(op.pro_part); p.pro_gamma = R.get<const float>(op.pro_gamma); p.pro_beta = R.get<const float>(op.pro_beta);
         p.m_part = R.get<const double>(op.m_part);
-        if (op.small_co > 0) {
+        if (op.small_co > 0 && op.head) {
+          if (op.fuse_blend && R.user[U_FUSE]) {
+            p.bl_img = reinterpret_cast<const float*>(R.user[U_IMG]); p.bl_dain = reinterpret_cast<const float*>(R.user[U_FAKE]);
+            p.bl_fuse = reinterpret_cast<float*>(const_cast<void*>(R.user[U_FUSE]));
+          }
+          launch_head(op.small_co, p.Cin, bf16, op.grid, st, p);
+        } else if (op.small_co > 0) {
           const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
           if (bf16) switch (op.small_co) {
             case 1: hipLaunchKernelGGL((k_conv_small<1, true>), op.grid, dim3(256), lds, st, p); break;
@@ -1684,6 +1706,12 @@ size_t rib_workspace_bytes(rib_handle* h, int B, int H, int W) {
 int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
                 const float* img_prev, float* img, float* mask, void* workspace, size_t workspace_bytes,
                 void* hip_stream) {
+  return rib_forward_blend(h, B, H, W, label, img_fake, img_prev, img, mask, nullptr, workspace, workspace_bytes, hip_stream);
+}
+
+int rib_forward_blend(rib_handle* h, int B, int H, int W, const float* label, const float* img_fake,
+                      const float* img_prev, float* img, float* mask, float* fuse, void* workspace, size_t workspace_bytes,
+                      void* hip_stream) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!label || !img_fake || !img_prev || !img || !mask || !workspace) return fail(h, RIB_ERR_INVALID, "rib_forward: null pointer");
@@ -1692,7 +1720,14 @@ int rib_forward(rib_handle* h, int B, int H, int W, const float* label, const fl
   if (workspace_bytes < P->ws_bytes) return fail(h, RIB_ERR_WORKSPACE, fmt("workspace %zu < required %zu bytes", workspace_bytes, P->ws_bytes));
   Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
-  return run_plan(h, P, R, reinterpret_cast<hipStream_t>(hip_stream));
+  R.user[U_FUSE] = nullptr;
+  bool fused = false;       // does the plan's mask head carry the blend?
+  if (fuse)
+    for (const Op& op : P->ops) fused = fused || op.fuse_blend;
+  if (fused) R.user[U_FUSE] = fuse;
+  rc = run_plan(h, P, R, reinterpret_cast<hipStream_t>(hip_stream));
+  if (rc == RIB_OK && fuse && !fused) rc = rib_blend(h, B, h->g.c.image_nc, H, W, img, mask, img_fake, fuse, hip_stream);
+  return rc;
 }
 
 int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const float* mask,
@@ -1850,6 +1885,8 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
       if (rc) return rc;
     } else PL = nullptr;     // a caller that sized the workspace with rib_workspace_bytes: per-frame label work
   }
+  bool chain_fused = false;
+  for (const Op& op : P->ops) chain_fused = chain_fused || op.fuse_blend;
   const float* prev = key_frame;   // evaluator.py:240-244: a segment starts from the ground-truth key frame
   for (int t = 0; t < T; ++t) {
     if (PL) {
@@ -1870,10 +1907,13 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
     Resolver R; R.ws = wsb; R.blob = h->d_blob;
     R.user[U_LABEL] = labels + (size_t)t * lframe; R.user[U_FAKE] = dains + (size_t)t * frame; R.user[U_PREV] = prev;
     R.user[U_IMG] = img_t; R.user[U_MASK] = mask_t;
+    R.user[U_FUSE] = chain_fused ? fuse_t : nullptr;     // the mask head writes the blend itself when it can
     rc = run_plan(h, P, R, st, false, PL != nullptr);
     if (rc) return rc;
-    rc = rib_blend(h, B, c.image_nc, H, W, img_t, mask_t, dains + (size_t)t * frame, fuse_t, hip_stream);
-    if (rc) return rc;
+    if (!chain_fused) {
+      rc = rib_blend(h, B, c.image_nc, H, W, img_t, mask_t, dains + (size_t)t * frame, fuse_t, hip_stream);
+      if (rc) return rc;
+    }
     prev = fuse_t;                 // evaluator.py:252: prev_img = results['fuse'][-1]
   }
   return RIB_OK;
@@ -1970,8 +2010,8 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
   const Op& op = P->ops[idx];
   if (op.kind == OP_IGEMM && op.small_co > 0)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|direct 16x16 tile, %d output channels on the vector ALUs|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.small_co, op.flops);
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|%s 16x16 tile, %d output channels%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
   else if (op.kind == OP_IGEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB, op.flops);
@@ -2027,6 +2067,7 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   if (sub.ops.empty()) return fail(h, RIB_ERR_INVALID, fmt("rib_time_op: no op named '%s'", op_name));
   Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
+  R.user[U_FUSE] = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const bool was = h->profiling; h->profiling = false;
   rc = run_plan(h, &sub, R, st, true);   // warm-up

@@ -219,6 +219,24 @@ class Generator:
 
     forward = __call__
 
+    def forward_blend(self, label, label_prev, img_fake, img_prev):
+        """(img, mask, fuse): the forward plus the driver's blend fuse = img*mask + img_fake*(1-mask)
+        (evaluator.py:256-258) in one call; the mask head's kernel writes the fused frame."""
+        s = self.spec
+        label = self._prep(label, s.label_nc, "label")
+        B, _, H, W = label.shape
+        img_fake = self._prep(img_fake, s.image_nc, "img_fake", (B, H, W))
+        img_prev = self._prep(img_prev, s.image_nc, "img_prev", (B, H, W))
+        ws = self._workspace(B, H, W)
+        img = torch.empty((B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
+        fuse = torch.empty_like(img)
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._h, self._lib.rib_forward_blend(
+                self._h, B, H, W, _ptr(label), _ptr(img_fake), _ptr(img_prev), _ptr(img), _ptr(mask), _ptr(fuse),
+                _ptr(ws), ws.numel(), self._stream()))
+        return img, mask, fuse
+
     def chain(self, key_frame, labels, dains, want_all=True):
         """One autoregressive segment on device (evaluator.py:238-262):
         labels [T,B,label_nc,H,W], dains [T,B,image_nc,H,W], key_frame

@@ -516,25 +516,36 @@ def test_every_kernel_variant_is_correct_wherever_it_fits():
     assert accepted > 150 and seen_kw > 10 and seen_tb > 10, (tried, accepted, seen_kw, seen_tb)
 
 
-def test_direct_head_convolutions_agree_with_the_matrix_core_path(monkeypatch):
-    """conv_img (16 -> 3) and conv_mask.0 (32 -> 1) run as k_conv_small on the vector ALUs; with
-    RIB_NO_SMALLCONV they go through k_igemm's 16-column path.  Same frame either way, at an odd size too."""
+def test_head_convolutions_agree_across_their_three_kernels(monkeypatch):
+    """conv_img (16 -> 3) and conv_mask.0 (32 -> 1) run as k_conv_head (matrix cores, the nine taps as GEMM columns; the
+    mask head also writes the driver's blend); with RIB_NO_HEADCONV as k_conv_small (direct, vector ALUs); with
+    RIB_NO_SMALLCONV through k_igemm's 16-column path.  Same frame all three ways, at odd sizes too, and the fused
+    blend equals forward + rib_blend bit for bit."""
     spec, sd, _ = build("full", 0)
-    for (H, W, seed) in ((64, 64, 1), (48, 80, 2), (256, 256, 3)):
-        label, fake, prev = synth.make_inputs(spec, 1, H, W, seed)
+    for (B, H, W, seed) in ((1, 64, 64, 1), (2, 48, 80, 2), (1, 256, 256, 3), (1, 16, 16, 4)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        outs, launches = [], []
+        for env in (None, "RIB_NO_HEADCONV", "RIB_NO_SMALLCONV"):
+            monkeypatch.delenv("RIB_NO_HEADCONV", raising=False)
+            monkeypatch.delenv("RIB_NO_SMALLCONV", raising=False)
+            if env:
+                monkeypatch.setenv(env, "1")
+            G = rib.Generator(rib.hsm_gen_config()).eval(); G.load_state_dict(sd)
+            i1, m1, f1 = [t.clone() for t in G.forward_blend(label, None, fake, prev)]
+            i2, m2 = G(label, None, fake, prev)
+            assert torch.equal(i1, i2) and torch.equal(m1, m2)
+            assert torch.equal(f1, G.blend(i2, m2, fake))                 # fused blend (or the fallback launch) == rib_blend
+            outs.append((i1, m1)); launches.append(G.num_launches(B, H, W))
+            info = [o for o in G.launch_info(B, H, W) if o["name"] in ("conv_img", "flow_network_temp.conv_mask.0")]
+            assert all(("head" in o["tile"]) == (env is None) for o in info), (env, info)
+            torch.cuda.synchronize()
+            del G
         monkeypatch.delenv("RIB_NO_SMALLCONV", raising=False)
-        G1 = rib.Generator(rib.hsm_gen_config()).eval(); G1.load_state_dict(sd)
-        i1, m1 = [t.clone() for t in G1(label, None, fake, prev)]
-        n1 = G1._lib.rib_num_launches(G1._h, 1, H, W)
-        monkeypatch.setenv("RIB_NO_SMALLCONV", "1")
-        G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
-        i2, m2 = G2(label, None, fake, prev)
-        torch.cuda.synchronize()
         # (through k_igemm, conv_mask.0 may also finalise up_flow.5's statistics itself: one launch less)
-        assert n1 - G2._lib.rib_num_launches(G2._h, 1, H, W) in (0, 1)
-        e = max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max()))
-        assert e < 2e-6, (H, W, e)
-        del G1, G2
+        assert launches[0] == launches[1] and launches[1] - launches[2] in (0, 1)
+        for (i, m) in outs[1:]:
+            e = max(float((outs[0][0] - i).abs().max()), float((outs[0][1] - m).abs().max()))
+            assert e < (2e-6 if H >= 48 else 1e-5), (B, H, W, e)     # (a 1x1 deepest map amplifies rounding: see the edge-shape test)
 
 
 def test_upsample_convolutions_as_phase_convolutions_match_oracle_at_odd_sizes():
