@@ -1,14 +1,14 @@
 #!/bin/bash
 # Regenerate the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r01
+#   bash tools/refresh_profiles.sh r02
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[refresh] bench"; python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "[refresh] bench (default command)"; python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[refresh] rocprofv3 --stats of the bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_prof.log 2>&1
 cp $OUT/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
@@ -19,14 +19,20 @@ echo "[refresh] PMC passes (separate runs, kernel trace only)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_w.log 2>&1
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_traffic.json
-echo "[refresh] other shapes"
-for flags in "--mode chain --frames 32" "--dtype bf16 --mode chain --frames 32" "--dtype bf16" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024" "--size 256"; do
+echo "[refresh] other shapes and modes"
+rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
+for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype f32x3" "--dtype f32x3 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
+echo "[refresh] bf16 kernel stats (config 3)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --dtype bf16 --mode chain --frames 32 --steps 10 --warmup 2 > $OUT/${TAG}_bench_bf16_prof.log 2>&1
+cp $OUT/prof_bf16/bench_kernel_stats.csv $OUT/${TAG}_bench_bf16_kernel_stats.csv
+echo "[refresh] multi-rank rehearsal on one GPU (2 ranks share device 0, gloo instead of RCCL): BASELINE config 4 shape"
+cd $ROOT
+RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --mode clips --steps 3 --warmup 1 > $OUT/${TAG}_clips_2ranks_1gpu.json 2> $OUT/${TAG}_clips_2ranks_1gpu.err
+cd /tmp
 echo "[refresh] motion transformer"
 python3 $ROOT/tools/motion_bench.py --out $OUT/${TAG}_motion_bench.json > $OUT/${TAG}_motion_bench.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_motion -o motion -- python3 $ROOT/tools/motion_bench.py > $OUT/${TAG}_motion_prof.log 2>&1
-cp $OUT/prof_motion/motion_kernel_stats.csv $OUT/${TAG}_motion_kernel_stats.csv
-rm -rf $OUT/prof_bench $OUT/prof_ops $OUT/pmc_f $OUT/pmc_w $OUT/prof_motion
+rm -rf $OUT/prof_bench $OUT/prof_ops $OUT/pmc_f $OUT/pmc_w $OUT/prof_bf16
 echo "[refresh] done"
