@@ -152,15 +152,13 @@ struct IgemmParams {
   // launch less per normalised tensor.  part = [B][tiles][2][Cs] fp64: the producers' epilogues accumulate sum(x)
   // and sum(x^2) in fp64 from the element level, so E[x^2] - mean^2 does not cancel when |mean| >> std (an fp32
   // partial of x^2 loses the variance once mean^2 / var reaches ~1e6; torch's instance_norm does not).
-  const double* pro_part; int pro_tiles, pro_Cs; float pro_inv;  // prologue: replaces pro_scale / pro_shift
-  const float* pro_gamma; const float* pro_beta;                 //   IN affine of the producer (mask network), or nullptr
   const double* m_part; int m_tiles, m_Cs; float m_inv;          // SPADE epilogue: replaces m_scale / m_shift (no affine)
   // --- driver blend fused into the mask head (k_conv_head<1>): fuse = img*m + dain*(1-m), NCHW fp32 caller tensors
   // (PGNR/models/evaluator.py:256-258); all three null when the caller did not ask for the fused frame ---
   const float* bl_img; const float* bl_dain; float* bl_fuse; int bl_C;
 };
 
-enum { STATS_MAX_PARTIALS = 128, STATS_MAX_PRO_CH = 512 };
+enum { STATS_MAX_PARTIALS = 128 };
 
 // (scale, shift) of ONE channel from the per-tile partial sums of its producer; `base` points at the sample's
 // [tiles][2][Cs] block.  Same arithmetic as k_stats_finalize (fp64 sums in a fixed tile order, biased variance,
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
   // consumer-side InstanceNorm finalize: (scale, shift) of the input channels (prologue) / of this workgroup's
   // modulated channels (SPADE epilogue), reduced from the producer's partial sums at kernel start
-  __shared__ __attribute__((aligned(16))) float s_stat[(PRO && !SPADE) ? 2 * STATS_MAX_PRO_CH : (SPADE ? 2 * (G::BN / 2) : 4)];
+  __shared__ __attribute__((aligned(16))) float s_stat[SPADE ? 2 * (G::BN / 2) : 4];
   float* sA = smem;
   float* sB = smem + G::NA * G::SA;
 
@@ -414,18 +412,6 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
     iy = iy0 + ly; ix = ix0 + lx;
     return idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
   };
-  // prologue constants of chunk kc when they come from the consumer-side finalize (LDS, filled at kernel start)
-  auto pro_from_lds = [&](int kc) {
-    if constexpr (PRO && !SPADE) {
-      if (p.pro_part) {
-#pragma unroll
-        for (int q = 0; q < PV; ++q) {
-          psc[q] = *reinterpret_cast<const float4*>(s_stat + kc + ac4 * EPS + q * 4);
-          psh[q] = *reinterpret_cast<const float4*>(s_stat + STATS_MAX_PRO_CH + kc + ac4 * EPS + q * 4);
-        }
-      }
-    }
-  };
   auto prefetchA = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
@@ -444,7 +430,6 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
         }
       }
     }
-    pro_from_lds(kc);
   };
   // fused prologue on the way into LDS: InstanceNorm affine + LeakyReLU; conv zero padding is
   // applied AFTER the transform (the reference pads the activated tensor)
@@ -455,7 +440,7 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       const bool inb = slot_inb(i, pix, iy, ix);
       float4 v = areg[i];
       if constexpr (PRO) {
-        const bool aff = !raw && (p.pro_scale || p.pro_part), lr = !raw && p.pro_lrelu;
+        const bool aff = !raw && p.pro_scale, lr = !raw && p.pro_lrelu;
         if constexpr (BF16) {
           if (aff || lr) {        // 8 packed bf16 channels: unpack, fp32 prologue, round back
             const uint32_t w[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
@@ -511,20 +496,6 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
   // ---- consumer-side InstanceNorm finalize (see IgemmParams): called once, right after the first operand loads
   // have been issued, so that the partial-sum loads overlap them ----
   auto consumer_stats = [&]() {
-    if constexpr (PRO && !SPADE) {
-      if (p.pro_part) {
-        const double* base = p.pro_part + (size_t)n * p.pro_tiles * 2 * p.pro_Cs;
-        for (int c = tid; c < p.Cin; c += NT) {     // input channel c of x is channel c of its producer
-          double a1, a2;
-          stats_from_partials(base, p.pro_tiles, p.pro_Cs, c, 0, 1, a1, a2);
-          float sc, sh;
-          scale_shift_of(a1, a2, p.pro_inv, p.pro_gamma ? p.pro_gamma[c] : 1.f, p.pro_beta ? p.pro_beta[c] : 0.f, sc, sh);
-          s_stat[c] = sc; s_stat[STATS_MAX_PRO_CH + c] = sh;
-        }
-        __syncthreads();
-        pro_from_lds(kc_begin);
-      }
-    }
     if constexpr (SPADE) {
       if (p.m_part) {
         // this workgroup modulates the virtual channels n0/2 .. n0/2 + BN/2 - 1; thread = (channel j, tile slice)
@@ -941,11 +912,19 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
       }
     }
   } else if (!SPADE) {
-    double s1[NF], s2[NF];     // fp64 from the first add (see IgemmParams: no fp32 cancellation in E[x^2] - mean^2)
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) { s1[nf] = 0.0; s2[nf] = 0.0; }
+    // statistics partials: fp64 from the fragment level on (see IgemmParams: no fp32 cancellation in E[x^2] - mean^2).
+    // ONE accumulator pair is live at a time - a column fragment's sums go to LDS before the next one starts: a pair
+    // per fragment cost 4 more registers in the NF = 2 variants, i.e. 4 -> 3 waves per SIMD (96 + 32 -> 99 + 32)
+    double* red = reinterpret_cast<double*>(smem);   // [WM][BN][2]
+    if (p.stat_part) __syncthreads();                // all waves finished the main loop: smem can be reused
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
+      // sum(x), sum(x^2) of this lane's valid elements without cancellation at fp32 cost: deviations from a pivot (the
+      // lane's first value) are summed in fp32 - they are of the size of the spread, not of the mean - and the pivot is
+      // put back in fp64 once per column fragment:  sum x = k*p + sum d,  sum x^2 = k*p^2 + 2p*sum d + sum d^2
+      // (three live values per column fragment - round 1's fp32 sums had four across NF = 2 fragments and the NF = 2
+      // variants sit exactly on the 96 + 32 register boundary of 4 waves per SIMD; the element count is recomputed)
+      float pv = 0.f, d1 = 0.f, d2 = 0.f;
       const int col = n0 + (wn * NF + nf) * 32 + li;
       const bool cvalid = col < p.Cout;
       const float bv = (col < p.CoutPad) ? p.bias[col] : 0.f;
@@ -1010,21 +989,12 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           const bool ok = cvalid && oy < p.Hout && ox < p.Wout;
           okm |= ok ? (1u << r) : 0u;
         }
-        {
-          // sum(x), sum(x^2) of the fragment's valid elements, free of cancellation at fp32 cost: deviations from a
-          // pivot (the lane's first value) are summed in fp32 - they are of the size of the spread, not of the mean -
-          // and the pivot is put back once per fragment in fp64:  sum x = k*p + sum d,  sum x^2 = k*p^2 + 2p*sum d + sum d^2
-          const float pv = vv[0];
-          float d1 = 0.f, d2 = 0.f;
+        if (ph == 0 && mf == 0) pv = vv[0];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = (okm & (1u << r)) ? vv[r] - pv : 0.f;
-            d1 += d;
-            d2 += d * d;
-          }
-          const double k = (double)__popc(okm), pd = (double)pv;
-          s1[nf] += k * pd + (double)d1;
-          s2[nf] += (k * pd + 2.0 * (double)d1) * pd + (double)d2;
+        for (int r = 0; r < 16; ++r) {
+          const float d = (okm & (1u << r)) ? vv[r] - pv : 0.f;
+          d1 += d;
+          d2 += d * d;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1049,20 +1019,33 @@ __global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
           }
         }
       }
-    }
-    if (p.stat_part) {   // deterministic per-tile partial sums for the following InstanceNorm
-      __syncthreads();   // all waves finished the main loop: smem can be reused
-      double* red = reinterpret_cast<double*>(smem);   // [WM][BN][2]
+      if (p.stat_part) {
+        int cnt = 0;      // valid elements of this lane in this column fragment (coordinates only: nothing kept live for it)
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const double a1 = s1[nf] + __shfl_xor(s1[nf], 32);
-        const double a2 = s2[nf] + __shfl_xor(s2[nf], 32);
+        for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+              int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+              int ox = tx0 + row % FRW;
+              if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
+              cnt += (cvalid && oy < p.Hout && ox < p.Wout) ? 1 : 0;
+            }
+        const double k = (double)cnt, pd = (double)pv;
+        const double s1 = k * pd + (double)d1;
+        const double s2 = (k * pd + 2.0 * (double)d1) * pd + (double)d2;
+        const double a1 = s1 + __shfl_xor(s1, 32);
+        const double a2 = s2 + __shfl_xor(s2, 32);
         if (lh == 0) {
           const int c = (wn * NF + nf) * 32 + li;
           red[(wm * G::BN + c) * 2 + 0] = a1;
           red[(wm * G::BN + c) * 2 + 1] = a2;
         }
       }
+    }
+    if (p.stat_part) {   // deterministic per-tile partial sums for the following InstanceNorm
       __syncthreads();
       for (int c = tid; c < G::BN; c += 256) {
         double a1 = 0.0, a2 = 0.0;

@@ -266,7 +266,7 @@ struct Variant {
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
   if (p.x2 != nullptr) return v->fn;
-  if (p.pro_scale == nullptr && p.pro_part == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
+  if (p.pro_scale == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
   return v->fn_pro ? v->fn_pro : v->fn;
 }
 
@@ -371,7 +371,7 @@ struct Op {
   bool fuse_blend = false;   // the mask head also writes the driver's blend into user slot U_FUSE when the caller gave one
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
-  PRef pro_part, pro_gamma, pro_beta, m_part;   // consumer-side InstanceNorm finalize (IgemmParams)
+  PRef m_part;   // consumer-side InstanceNorm finalize in the SPADE epilogue (IgemmParams)
   // split-K epilogue
   SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
   // unfused SPADE modulate
@@ -712,15 +712,10 @@ struct Builder {
                        c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
                        !getenv("RIB_NO_SMALLCONV");
     if (a.pro) {
-      // consumer-side finalize: this launch reduces the producer's partial sums in its prologue
-      if (has_partials(*a.pro) && a.pro_choff == 0 && !small && c.cinp <= STATS_MAX_PRO_CH && c.cinp <= a.pro->pend->Cs) {
-        const PendingStats& ps = *a.pro->pend;
-        op.pro_part = WS(ps.part_off); p.pro_tiles = ps.tiles; p.pro_Cs = ps.Cs; p.pro_inv = ps.inv_count;
-        if (ps.affine) { op.pro_gamma = WT(ps.g_off); op.pro_beta = WT(ps.be_off); }
-      } else {
-        materialize(*a.pro, opname);
-        op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float));
-      }
+      // (a consumer-side finalize in the PROLOGUE was tried and removed: its (scale, shift) table cost every prologue
+      // variant 4 KB of LDS - an occupancy step for several of them - to save four launches; the SPADE epilogue keeps its own)
+      materialize(*a.pro, opname);
+      op.pro_scale = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.pro_shift = WS(a.pro->sh + a.pro_choff * sizeof(float));
     }
     // matrix-core kernels of a bf16 handle read the bf16 filter copies; the direct head convolutions keep fp32 filters
     const bool w16 = h->mc16() && !small;
@@ -950,7 +945,7 @@ struct Builder {
 
   template <typename F> static void for_each_pref(Op& op, F f) {
     PRef* all[] = {&op.x, &op.pro_scale, &op.pro_shift, &op.w, &op.bias, &op.y, &op.res, &op.y_nchw, &op.stat, &op.xm, &op.m_scale,
-                   &op.m_shift, &op.ys0, &op.ys1, &op.slab, &op.x2, &op.w2, &op.pro_part, &op.pro_gamma, &op.pro_beta, &op.m_part,
+                   &op.m_shift, &op.ys0, &op.ys1, &op.slab, &op.x2, &op.w2, &op.m_part,
                    &op.s_slab, &op.s_bias, &op.s_y, &op.s_res, &op.s_stat, &op.m_slab, &op.m_bias, &op.m_xm, &op.m_sc, &op.m_sh,
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
                    &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst};
@@ -1334,7 +1329,6 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.x2 = R.get<const float>(op.x2); p.w2 = R.get<const float>(op.w2);
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
-        p.pro_part = R.get<const double>(op.pro_part); p.pro_gamma = R.get<const float>(op.pro_gamma); p.pro_beta = R.get<const float>(op.pro_beta);
         p.m_part = R.get<const double>(op.m_part);
         if (op.small_co > 0 && op.head) {
           if (op.fuse_blend && R.user[U_FUSE]) {
