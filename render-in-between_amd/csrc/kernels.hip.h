@@ -257,7 +257,12 @@ struct IgemmGeom {
 // multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, int PREC = 0,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
-__global__ __launch_bounds__(256 * KW) void k_igemm(const IgemmParams p) {
+// Second launch bound = minimum waves per SIMD the register allocator must leave room for.  The fp32 variants with
+// two column fragments per wave (NF = 2: 32 accumulator registers) sit exactly on the 128-register boundary of 4 waves
+// per SIMD; one more live value in an epilogue made the allocator give up and settle at 3 (97 + 32 registers), which
+// cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
+// and fits 99-104 registers without spilling.
+__global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC> G;
   constexpr bool BF16 = G::BF16, X3 = G::X3;
   constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored activation element
