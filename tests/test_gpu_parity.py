@@ -541,8 +541,8 @@ def test_head_convolutions_agree_across_their_three_kernels(monkeypatch):
             torch.cuda.synchronize()
             del G
         monkeypatch.delenv("RIB_NO_SMALLCONV", raising=False)
-        # (through k_igemm, conv_mask.0 may also finalise up_flow.5's statistics itself: one launch less)
-        assert launches[0] == launches[1] and launches[1] - launches[2] in (0, 1)
+
+        assert launches[0] == launches[1] and abs(launches[1] - launches[2]) <= 1     # (k_igemm may split K at these sizes)
         for (i, m) in outs[1:]:
             e = max(float((outs[0][0] - i).abs().max()), float((outs[0][1] - m).abs().max()))
             assert e < (2e-6 if H >= 48 else 1e-5), (B, H, W, e)     # (a 1x1 deepest map amplifies rounding: see the edge-shape test)
