@@ -250,6 +250,12 @@ def main():
             break
     # f32x3 runs six bf16 MFMAs per fp32-equivalent 16-channel step: its ceiling for fp32-equivalent FLOPs is 1/6 of the bf16 peak
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.dtype]
+    # fused-minimum HBM model of SURVEY 8(d) (every conv reads its input and writes its output once, one extra read per
+    # normalised tensor, one cond read per SPADE layer, weights once): 2.82 GB per 512x512 fp32 frame, of which 0.123 GB
+    # are weights; activations scale with the pixel count, bf16 storage halves everything
+    px = B * H * W / (512.0 * 512.0)
+    alg_bytes = (2.694e9 * px + 0.123e9) * (0.5 if args.dtype == "bf16" else 1.0)
+    hbm_gbs = alg_bytes * (frames_per_step / B) / (ms_per_step * 1e-3) / 1e9
     roofline = {
         "bound": "mfma",
         # the convolution class: k_igemm on the matrix cores; at fp32 the 1..4-channel heads (conv_img, conv_mask.0:
@@ -268,7 +274,15 @@ def main():
         "classes": classes,
         "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) * (frames_per_step / B) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
+        "whole_step_algorithmic_hbm_gbs": hbm_gbs, "whole_step_frac_of_hbm_roof": hbm_gbs / PEAK_HBM_GBS,
     }
+    if args.dtype == "bf16":
+        # with bf16 matrix cores (2.5 PFLOP/s) the frame's roof is HBM (0.18 ms at 512x512): report against that;
+        # the matrix-core figures of the convolution class stay in the object for reference
+        roofline.update({"bound": "hbm", "mfma_achieved_tflops": conv_tflops, "mfma_frac": conv_tflops / peak,
+                         "kernel": "whole frame (the bf16 frame is bound by HBM, not by any one kernel): fused-minimum bytes of SURVEY 8(d) / frame time",
+                         "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                         "algorithmic_bytes_per_frame": alg_bytes})
 
     log("profile pass done: conv %.3f ms/step" % conv_ms)
     # ---- parity on the bench inputs + CPU baseline (oracle timed on the host cores) ----

@@ -754,6 +754,52 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         compute_tap(dy, 2, buf * 3 + 2);
       }
     }
+  } else if constexpr ((RIB_EXP & 32) && KS == 1 && STRIDE == 1 && !UPS && PREC == PREC_F32 && TB == 1 && KW == 1 && !N16) {
+    // EXPERIMENT (tools/probes/spade_harness.hip, -DRIB_EXP=32): 1x1 convolutions have no halo, so with WN == 1 every
+    // input pixel is used by exactly one wave and staging it through LDS buys no reuse: read the A fragments straight
+    // from global memory in MFMA operand layout (lane = pixel li, channels kb*8 + lh*4 .. +3), double-buffered in
+    // registers; only the filters go through LDS (one barrier per chunk)
+    size_t pixoff[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+      pixoff[mf] = (size_t)(min(ty0 + fy[mf], p.Hin - 1) * p.Win + min(tx0 + fx, p.Win - 1)) * p.xC * 4;
+    float4 afr[2][MF][BK / 8];
+    auto loadAf = [&](int kc, int b) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb)
+          afr[b][mf][kb] = *reinterpret_cast<const float4*>(xn + pixoff[mf] + (size_t)(kc + kb * 8 + lh * 4) * 4);
+    };
+    loadB(kc_begin, 0);
+    loadAf(kc_begin, 0);
+    consumer_stats();
+    int st = 0;
+#pragma unroll 2
+    for (int kc = kc_begin; kc < kc_end; kc += BK, ++st) {
+      const int buf = st & 1;
+      storeB(buf);
+      if (kc + BK < kc_end) { loadB(kc + BK, 0); loadAf(kc + BK, buf ^ 1); }
+      __syncthreads();
+      const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
+#pragma unroll
+      for (int kb = 0; kb < BK / 8; ++kb) {
+        float4 b[NFE];
+#pragma unroll
+        for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NFE; ++nf) {
+            const float4 a = afr[buf][mf][kb];
+            f32x16& d = acc[mf][nf];
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nf].x, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nf].y, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nf].z, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nf].w, d, 0, 0, 0);
+          }
+      }
+    }
   } else {
   loadB(kc_begin, 0);
   prefetchA(kc_begin);

@@ -206,3 +206,15 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
                 stale.append((shape, op, ch))
             assert int(ch[10]) >= 1
     assert not stale, stale[:5]
+    # the bf16-storage and f32x3 modes have tables of their own, measured on their own kernels
+    for dtype in ("bf16", "f32x3"):
+        geoms = set()
+        for i in range(lib.rib_num_variants()):
+            if lib.rib_variant_info(i, g12) == tuning.PREC[dtype]:
+                geoms.add(tuple(g12))
+        assert len(geoms) >= 40, (dtype, len(geoms))
+        table = tuning.load(dtype=dtype)
+        assert "1,512,512" in table and len(table["1,512,512"]) >= 50, dtype
+        stale = [(shape, op) for shape, entry in table.items() for op, ch in entry.items()
+                 if tuple(ch[:10]) + (int(ch[11]), int(ch[12])) not in geoms]
+        assert not stale, (dtype, stale[:5])
