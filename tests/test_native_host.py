@@ -143,6 +143,35 @@ def test_partial_reload_after_finalize_folds_old_and_new_tensors(lib):
     lib.rib_destroy(h)
 
 
+def test_precision_mode_switch_refolds_the_weights(lib):
+    """rib_set_compute_dtype changes the blob layout (bf16: 16-channel minimum, bf16 filter copies; f32x3: three-plane
+    copies).  A handle that still holds the state-dict tensors re-folds by itself; the fp32 section still undoes to the
+    oracle's fold; plans of every mode build at odd sizes; an unknown mode is refused."""
+    cfg = rib.hsm_gen_config(**MID_CFG)
+    spec, h = host_handle(lib, cfg)
+    sd = synth.make_state_dict(spec, 21)
+    for k, v in sd.items():
+        t = v.contiguous()
+        d = (C.c_int64 * t.dim())(*t.shape)
+        assert lib.rib_set_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), d) == 0
+    assert lib.rib_finalize_weights(h) == 0
+    n32 = lib.rib_weights_bytes(h)
+    sizes = {}
+    for mode in (1, 2, 0):
+        assert lib.rib_set_compute_dtype(h, mode) == 0, lib.rib_last_error(h)
+        sizes[mode] = lib.rib_weights_bytes(h)
+        for cname in ("ref_embedding.conv_first", "down_1.conv_block_0", "conv_img"):
+            w_ref, b_ref = generator_ref.conv_weight(sd, cname)
+            w = np.empty(tuple(w_ref.shape), np.float32); b = np.empty(w_ref.shape[0], np.float32)
+            assert lib.rib_debug_conv_weight(h, cname.encode(), w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0, lib.rib_last_error(h)
+            assert np.abs(w - w_ref.numpy()).max() <= 2e-6 * float(w_ref.abs().max()), (mode, cname)
+        for (B, H, W) in ((1, 64, 64), (2, 48, 80), (1, 16, 16)):
+            assert lib.rib_workspace_bytes(h, B, H, W) > 0, (mode, lib.rib_last_error(h))
+    assert sizes[0] == n32 and sizes[1] > 1.4 * n32 and sizes[2] > sizes[1]       # + bf16 copies / + three-plane copies
+    assert lib.rib_set_compute_dtype(h, 7) != 0
+    lib.rib_destroy(h)
+
+
 def test_plan_flops_and_shape_rules(lib):
     spec, h = host_handle(lib, rib.hsm_gen_config())
     fl = (C.c_double * 6)()

@@ -3,6 +3,7 @@
 Uses only the entry points every build since round 1 exports (create, set_tensor, finalize, set_choice, forward, blend).
 
     python3 tools/ab_lib.py --tuning render-in-between_amd/tuning_gfx950.json lib_a.so lib_b.so ...
+(tools/tuning_r01.json is round 1's table: the common ground when a build from round 1 is one of the contestants)
 """
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
