@@ -27,10 +27,10 @@ import render_in_between_amd as rib                                   # noqa: E4
 from render_in_between_amd.evaluator import Evaluator                 # noqa: E402
 
 
-def load_generator(config, device=None, rank=0, world=1):
+def load_generator(config, device=None, rank=0, world=1, dtype="f32"):
     """trainer.net_G with its checkpoint (PGNR/models/trainer.py:61,67; utils/utils.py:107-119).  With several
     ranks only rank 0 touches the file; the others receive the folded weights (distributed.broadcast_weights)."""
-    net_G = rib.Generator(config.gen, device=device)
+    net_G = rib.Generator(config.gen, device=device, compute_dtype=dtype)
     path = config.model_pretrain_G
     if not os.path.isfile(path):
         raise ValueError("=> No checkpoint found at '{}'".format(path))
@@ -63,7 +63,7 @@ def main(opts):
         device = torch.device("cuda", int(os.environ.get("RIB_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
         torch.cuda.set_device(device)
         ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"))
-    net_G = load_generator(config, device, rank, world)
+    net_G = load_generator(config, device, rank, world, opts.dtype)
     evaluator = Evaluator(config)
     train_dir = os.path.join(opts.input_dir, "inputs")
     dain_dir = os.path.join(opts.input_dir, "DAIN")
@@ -82,5 +82,8 @@ if __name__ == "__main__":
     parser.add_argument("--save-dir", type=str, default="../example", help="outputs path")
     parser.add_argument("--input-dir", type=str, required=True, help="input low FPS frames and pose input")
     parser.add_argument("--seed", type=int, default=123)
+    parser.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32",
+                        help="f32: the reference's arithmetic (default); bf16: bf16 storage, ~2x the frame rate, ~1e-2 mean deviation "
+                             "(not in the reference: it is fp32 only)")
     parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")
     main(parser.parse_args())
