@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""The product's multi-GPU path, end to end, on whatever GPUs the box has: writes a synthetic example folder
+(inputs / DAIN / Predict_motion, two clips) and a seed-defined checkpoint, runs `inference.py` once with one rank and once
+with N ranks (the CLI starts its own ranks; on a 1-GPU box set RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo so that all ranks
+share the device), and compares the written PNGs byte for byte.  This process never touches the GPU: the CLIs run as
+child processes.
+
+    RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 tools/multirank_inference_check.py --gpus 2 [--dtype f32]
+"""
+import argparse, json, os, shutil, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import yaml
+
+
+def write_clip(root, clip, n_key, rate, H, W, seed):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    n = (n_key - 1) * rate + 1
+    for d in ("inputs", "DAIN", "Predict_motion"):
+        os.makedirs(os.path.join(root, d, clip))
+    for k in range(n_key):
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "inputs", clip, "%04d.png" % k))
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "DAIN", clip, "f%03d.png" % i))
+        body = []
+        for j in range(25):
+            body += [float(rng.uniform(4, W - 4)), float(rng.uniform(4, H - 4)), 0.9]
+        hand = [10.0, 10.0, 0.9] * 21
+        with open(os.path.join(root, "Predict_motion", clip, "f%03d_keypoints.json" % i), "w") as f:
+            json.dump({"people": [{"pose_keypoints_2d": body, "hand_left_keypoints_2d": hand, "hand_right_keypoints_2d": hand}]}, f)
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=2)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--size", type=int, nargs=2, default=[128, 192])
+    a = ap.parse_args()
+    import render_in_between_amd as rib
+    from render_in_between_amd import synth
+    tmp = tempfile.mkdtemp(prefix="rib_mr_")
+    H, W = a.size
+    n = write_clip(tmp, "clipA", 4, 4, H, W, 1) + write_clip(tmp, "clipB", 3, 2, H, W, 2)      # 3 + 2 segments, 13 + 5 frames
+    spec = rib.GenSpec.from_cfg(rib.hsm_gen_config())
+    ck = os.path.join(tmp, "netG.pth")
+    torch.save(synth.make_state_dict(spec, 3), ck)
+    cfg = yaml.load(open(os.path.join(ROOT, "render-in-between_amd", "configs", "HSM.yaml")), Loader=yaml.FullLoader)
+    cfg["model_pretrain_G"] = ck; cfg["model_height"] = H; cfg["model_width"] = W
+    cpath = os.path.join(tmp, "cfg.yaml")
+    yaml.dump(cfg, open(cpath, "w"))
+    cli = os.path.join(ROOT, "render-in-between_amd", "inference.py")
+    res = {}
+    for g in (1, a.gpus):
+        out = os.path.join(tmp, "out%d" % g)
+        t0 = time.time()
+        r = subprocess.run([sys.executable, cli, "--config", cpath, "--input-dir", tmp, "--save-dir", out, "--gpus", str(g), "--dtype", a.dtype],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-2000:], r.stderr[-4000:]); raise SystemExit("inference.py --gpus %d failed (rc %d)" % (g, r.returncode))
+        res[g] = (out, time.time() - t0, [l for l in r.stdout.splitlines() if "rank" in l or "broadcast" in l])
+    files = sorted(os.path.relpath(os.path.join(d, f), res[1][0]) for d, _, fs in os.walk(res[1][0]) for f in fs)
+    assert len(files) == n, (len(files), n)
+    same = 0
+    for f in files:
+        same += open(os.path.join(res[1][0], f), "rb").read() == open(os.path.join(res[a.gpus][0], f), "rb").read()
+    print(json.dumps({"frames": n, "ranks": a.gpus, "dtype": a.dtype, "size": [H, W], "png_files_byte_identical": same,
+                      "all_identical": same == n, "seconds_1_rank": round(res[1][1], 2), "seconds_%d_ranks" % a.gpus: round(res[a.gpus][1], 2),
+                      "rank_lines": res[a.gpus][2]}))
+    shutil.rmtree(tmp)
+    if same != n:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
