@@ -48,11 +48,12 @@ def main():
     ap.add_argument("--keys", type=int, default=3)
     ap.add_argument("--rate", type=int, default=32)
     ap.add_argument("--lanes", type=int, default=3)
+    ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
     H = W = a.size
     cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=H, model_width=W, gauss_sigma=5, skeleton_thres=0.001, foot_thres=0.001)
     spec = rib.GenSpec.from_cfg(cfg.gen)
-    G = rib.Generator(cfg.gen).eval()
+    G = rib.Generator(cfg.gen, compute_dtype=a.dtype).eval()
     G.load_state_dict(synth.make_state_dict(spec, 0, power_iters=3))
     with tempfile.TemporaryDirectory() as root:
         n = write_clip(root, a.keys, a.rate, H, W)
@@ -64,7 +65,7 @@ def main():
             wall = time.perf_counter() - t0
         tm = dict(E.timings)
     gen = n - a.keys
-    print(json.dumps({"size": a.size, "frames": n, "generated": gen, "lanes": a.lanes, "io_threads": E.io_threads,
+    print(json.dumps({"size": a.size, "dtype": a.dtype, "frames": n, "generated": gen, "lanes": a.lanes, "io_threads": E.io_threads,
                       "wall_s": wall, "frames_per_s_end_to_end": n / wall,
                       "phase_s": {k: round(v, 4) for k, v in tm.items() if k != "frames"},
                       "generate_frames_per_s": gen / tm["generate"]}))
