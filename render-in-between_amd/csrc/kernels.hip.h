@@ -156,6 +156,9 @@ struct IgemmParams {
   // --- driver blend fused into the mask head (k_conv_head<1>): fuse = img*m + dain*(1-m), NCHW fp32 caller tensors
   // (PGNR/models/evaluator.py:256-258); all three null when the caller did not ask for the fused frame ---
   const float* bl_img; const float* bl_dain; float* bl_fuse; int bl_C;
+  // --- batched GEMM with one filter set per "sample" (the 16 Winograd positions: k_wino_in / k_wino_out): sample n
+  // reads the filters at w + (n % w_mod) * w_stride elements; w_mod = 0: one filter set for all samples ---
+  int w_mod; unsigned w_stride;
 };
 
 enum { STATS_MAX_PARTIALS = 128 };
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
   }
 
   const char* xn = reinterpret_cast<const char*>(p.x) + (size_t)n * p.Hin * p.Win * p.xC * ESZ;
-  const char* wb = reinterpret_cast<const char*>(p.w);
+  const char* wb = reinterpret_cast<const char*>(p.w) + (p.w_mod ? (size_t)(n % p.w_mod) * p.w_stride * WSZ : 0);
   const int wrow = G::TAPS * p.Cin;   // elements per filter row (f32x3: per plane)
   // byte offset of the 16-byte slot g of filter row `row`, slice `tap`, chunk kc.  fp32 / bf16: [row][tap][Cin];
   // f32x3: [row][tap][plane][Cin] bf16, slot g = plane * (BK / 8) + group
@@ -1332,6 +1335,167 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the 3x3 stride-1 convolutions on the <= 64x64 maps (round 2).  At batch 1 those layers
+// cannot fill 256 CUs (a 32x32 map is 8 spatial tiles) and run as split-K launches of short workgroups; they are half
+// of the frame.  In the Winograd domain the convolution is 16 independent GEMMs [2x2-tiles x Cin] . [Cin x Cout] - one
+// per position of the 4x4 transformed tile - with 4/9 of the multiplications:
+//     V = B^T d B  (k_wino_in: 4x4 input tile d at offset (2ty-1, 2tx-1), prologue + zero padding applied first)
+//     M[xi] = V[xi] . U[xi],  U = G g G^T folded on the host (rib_finalize_weights)     (ONE k_igemm launch, KS = 1,
+//             16*B "samples" of a tilesY x tilesX "image", filter set per sample: IgemmParams::w_mod)
+//     Y = A^T M A  (k_wino_out: 2x2 outputs per tile, + bias, residual, activation, statistics partials)
+// The GEMM launch has 16x the independent rows of the direct convolution, so it fills the chip without split-K, and V
+// and M (4x the activation each) stay in L2 / the memory-side cache at these sizes.  fp32 throughout: the transforms
+// only add and halve, max |diff| to the direct kernel ~3e-6 on O(1) outputs (round 1's probe).
+// Layouts: V [B*16][tilesY][tilesX][Cin], M [B*16][tilesY][tilesX][CoutPad], sample index = n*16 + xi, xi = 4*row + col.
+// ---------------------------------------------------------------------------------------------
+struct WinoInParams {
+  const float* x; int H, W, xC, Cin;        // input activation [B][H][W][xC], Cin channels used (multiple of 4)
+  const float* pro_scale; const float* pro_shift; int pro_ld, pro_lrelu;   // optional prologue (as k_igemm's)
+  float* v; int tilesY, tilesX;
+};
+
+__global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
+  const int c4n = p.Cin / 4;
+  const int n = blockIdx.y;
+  const int ntiles = p.tilesY * p.tilesX;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n; i += gridDim.x * 256) {
+    const int c4 = i % c4n, tile = i / c4n;
+    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pro_scale) {
+      sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+      sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+    }
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        d[r][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+        float4 v = d[r][q];
+        if (p.pro_scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+        if (p.pro_lrelu) v = lrelu4(v);
+        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+        d[r][q] = v;
+      }
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+    float4 t[4][4];
+#define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
+#define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[0][q] = RIB_F4_SUB(d[0][q], d[2][q]);
+      t[1][q] = RIB_F4_ADD(d[1][q], d[2][q]);
+      t[2][q] = RIB_F4_SUB(d[2][q], d[1][q]);
+      t[3][q] = RIB_F4_SUB(d[1][q], d[3][q]);
+    }
+    const size_t plane = (size_t)ntiles * p.Cin;              // one position's [tiles][Cin] matrix
+    float* vb = p.v + (size_t)n * 16 * plane + (size_t)tile * p.Cin + c4 * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 0) * plane) = RIB_F4_SUB(t[r][0], t[r][2]);
+      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 1) * plane) = RIB_F4_ADD(t[r][1], t[r][2]);
+      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 2) * plane) = RIB_F4_SUB(t[r][2], t[r][1]);
+      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 3) * plane) = RIB_F4_SUB(t[r][1], t[r][3]);
+    }
+  }
+}
+
+struct WinoOutParams {
+  const float* m; int tilesY, tilesX, CoutPad;   // M [B*16][tiles][CoutPad]
+  const float* bias;
+  float* y; int yC, yoff, Cout, Hout, Wout;
+  int act;
+  const float* res; int resC;
+  double* stat_part; int blocks;                  // [B][blocks][2][CoutPad]
+};
+
+// grid (blocks, B); thread = (tile slot, 4 channels); a block covers 256 / (CoutPad/4) tiles
+__global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
+  __shared__ __attribute__((aligned(16))) double red[2][256][4];
+  const int c4n = p.CoutPad / 4;
+  const int slots = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
+  const int n = blockIdx.y;
+  const int ntiles = p.tilesY * p.tilesX;
+  const int tile = blockIdx.x * slots + slot;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tile < ntiles && slot < slots) {
+    const size_t plane = (size_t)ntiles * p.CoutPad;
+    const float* mb = p.m + (size_t)n * 16 * plane + (size_t)tile * p.CoutPad + c4 * 4;
+    float4 mm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mm[r][q] = *reinterpret_cast<const float4*>(mb + (size_t)(r * 4 + q) * plane);
+    // A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]
+    float4 u[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u[0][q] = RIB_F4_ADD(RIB_F4_ADD(mm[0][q], mm[1][q]), mm[2][q]);
+      u[1][q] = RIB_F4_SUB(RIB_F4_SUB(mm[1][q], mm[2][q]), mm[3][q]);
+    }
+    float4 yv[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      yv[r][0] = RIB_F4_ADD(RIB_F4_ADD(u[r][0], u[r][1]), u[r][2]);
+      yv[r][1] = RIB_F4_SUB(RIB_F4_SUB(u[r][1], u[r][2]), u[r][3]);
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+    float rr[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int oy = min(2 * ty + r, p.Hout - 1), ox = min(2 * tx + q, p.Wout - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rr[r][q][e] = p.res ? p.res[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+      }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int oy = 2 * ty + r, ox = 2 * tx + q;
+        const bool inb = oy < p.Hout && ox < p.Wout;
+        const float v4[4] = {yv[r][q].x + bv.x, yv[r][q].y + bv.y, yv[r][q].z + bv.z, yv[r][q].w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = apply_act(v4[e] + rr[r][q][e], p.act);
+          const bool ok = inb && c4 * 4 + e < p.Cout;
+          if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
+          t = ok ? t : 0.f;
+          s1[e] += (double)t; s2[e] += (double)t * (double)t;
+        }
+      }
+  }
+  if (p.stat_part) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
+      const int g = c / 4, e = c % 4;
+      double a1 = 0.0, a2 = 0.0;
+      for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
+      double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
+      dst[c] = a1;
+      dst[p.CoutPad + c] = a2;
+    }
+  }
+}
+#undef RIB_F4_SUB
+#undef RIB_F4_ADD
 
 // ---------------------------------------------------------------------------------------------
 // k_spade_modulate: second half of an UNFUSED SPADE (used where the map is small and the fused

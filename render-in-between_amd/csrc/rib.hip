@@ -103,6 +103,9 @@ struct ConvDef {
   int cinp = 0, coutp = 0;
   // bf16 storage mode: bf16 copies of the filters (same [CoutPad][tap][CinPad] layout), offsets in floats of the blob
   size_t w16_off = 0, wp16_off = 0;
+  // Winograd F(2x2, 3x3) filters U = G g G^T, [16 positions][CoutPad][CinPad] fp32, and a zero bias vector for the
+  // batched GEMM (the real bias is added by the output transform); 0: the layer never runs that way
+  size_t wu_off = 0, zero_off = 0;
 };
 
 struct TensorDef {
@@ -337,7 +340,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
-enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE };
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE, OP_WINO_IN, OP_WINO_OUT };
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
@@ -386,6 +389,10 @@ struct Op {
   InAddParams ap; PRef a_t1, a_sc1, a_sh1, a_ts, a_scs, a_shs, a_x, a_out;
   // pack
   PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
+  // Winograd transforms
+  WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v;
+  WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
+  bool wino = false;   // this k_igemm launch is the 16-way batched Winograd-domain GEMM (executes 4/9 of its nine-tap FLOP count)
 };
 
 struct PendingStats {
@@ -522,6 +529,16 @@ void assign_weight_layout(rib_handle* h) {
     sg.b_off = take(sg.npad);
     h->spade_index[sg.key] = (int)h->spades.size();
     h->spades.push_back(sg);
+  }
+  for (auto& c : h->convs) { c.wu_off = 0; c.zero_off = 0; }
+  if (h->prec() == PREC_F32 && !getenv("RIB_NO_WINO")) {
+    // 3x3 stride-1 convolutions with >= 128 input channels that own their launch (no fused 1x1 shortcut, no upsampled
+    // input): the deep residual blocks of the generator and of the mask network
+    for (auto& c : h->convs) {
+      if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 128 || c.cout < 64 || c.cinp % 32 || 256 % (c.coutp / 4)) continue;
+      c.wu_off = take((size_t)16 * c.coutp * c.cinp);
+      c.zero_off = take(c.coutp);
+    }
   }
   if (h->mc16()) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float); f32x3: three planes
     const size_t pl = h->compute_x3 ? 3 : 1;
@@ -672,6 +689,13 @@ struct Builder {
     const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
     const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
+    {
+      // Winograd F(2x2, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h)
+      static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 4096;
+      if (h->prec() == PREC_F32 && c.wu_off && !a.ups && !a.aux && !a.res_ups && a.y_nchw.sp == PS_NULL && a.y_user.sp == PS_NULL &&
+          (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2)
+        return conv_wino(a, opname, Hout, Wout);
+    }
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
@@ -791,6 +815,82 @@ struct Builder {
       // (a channel offset means two producers share the arrays - the concatenated encoders of the mask network -
       // and consumers would need two partial sources: those keep their launch)
       finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
+    }
+    return true;
+  }
+
+  bool conv_wino(const ConvArgs& a, const std::string& opname, int Hout, int Wout) {
+    const ConvDef& c = *a.cd;
+    const int tilesY = (Hout + 1) / 2, tilesX = (Wout + 1) / 2, ntiles = tilesY * tilesX;
+    const std::string gname = opname + ".wino";
+    const size_t v_off = alloc((size_t)B * 16 * ntiles * c.cinp * sizeof(float));
+    const size_t m_off = alloc((size_t)B * 16 * ntiles * c.coutp * sizeof(float));
+    {   // input transform (with the convolution's prologue)
+      Op op; op.kind = OP_WINO_IN; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_in"; op.for_op = gname;
+      memset(&op.wi, 0, sizeof op.wi);
+      op.wi.H = a.in.H; op.wi.W = a.in.W; op.wi.xC = a.in.Cp; op.wi.Cin = c.cinp; op.wi.tilesY = tilesY; op.wi.tilesX = tilesX;
+      op.wi.pro_lrelu = a.pro_lrelu ? 1 : 0;
+      op.wi_x = WS(a.in.off); op.wi_v = WS(v_off);
+      if (a.pro) {
+        materialize(*a.pro, gname);
+        op.wi.pro_ld = a.pro->ld;
+        op.wi_sc = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.wi_sh = WS(a.pro->sh + a.pro_choff * sizeof(float));
+      }
+      const size_t total = (size_t)ntiles * (c.cinp / 4);
+      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096), B, 1);
+      push(op);
+    }
+    {   // the 16 GEMMs as one 1x1 "convolution" of 16*B samples of a tilesY x tilesX image, one filter set per position
+      Choice ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * 16, tilesY, tilesX, c.cinp, false, 0, false);
+      auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, gname.c_str()));
+      if (it != h->choices.end()) {
+        const Variant& tv = kVariants[it->second.first];
+        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || tv.SPADE || tv.NF == 0 || c.cinp % tv.BK != 0 || it->second.second != 1) {
+          error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", gname.c_str(), it->second.first, it->second.second); return false;
+        }
+        ch.v = &tv; ch.ksplit = 1;
+      }
+      const Variant* v = ch.v;
+      if (!v) { error = gname + ": no 1x1 kernel variant"; return false; }
+      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = gname; op.var = v; op.wino = true;
+      IgemmParams& p = op.ip;
+      memset(&p, 0, sizeof p);
+      p.Hin = tilesY; p.Win = tilesX; p.xC = c.cinp; p.Cin = c.cinp; p.CoutPad = c.coutp; p.Hout = tilesY; p.Wout = tilesX;
+      p.tilesX = (tilesX + v->TW() - 1) / v->TW(); p.tilesY = (tilesY + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+      p.act = ACT_NONE; p.ksplit = 1; p.yC = c.coutp; p.yoff = 0; p.Cout = c.coutp;
+      p.w_mod = 16; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
+      op.x = WS(v_off); op.w = WT(c.wu_off); op.bias = WT(c.zero_off); op.y = WS(m_off);
+      op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * 16);
+      op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 of it)
+      P->flops[RIB_KC_IGEMM] += op.flops;
+      push(op);
+    }
+    {   // output transform + the convolution's epilogue
+      Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_out"; op.for_op = gname;
+      memset(&op.wo, 0, sizeof op.wo);
+      const int slots = 256 / (c.coutp / 4), blocks = (ntiles + slots - 1) / slots;
+      op.wo.tilesY = tilesY; op.wo.tilesX = tilesX; op.wo.CoutPad = c.coutp; op.wo.blocks = blocks;
+      op.wo.yC = a.out.Cp; op.wo.yoff = a.yoff; op.wo.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
+      op.wo.Hout = Hout; op.wo.Wout = Wout; op.wo.act = a.act;
+      if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
+      op.wo_m = WS(m_off); op.wo_bias = WT(c.b_off); op.wo_y = WS(a.out.off);
+      if (a.res) { op.wo_res = WS(a.res->off); op.wo.resC = a.res->Cp; }
+      size_t part_off = 0;
+      if (a.want_stats) { part_off = alloc((size_t)B * blocks * 2 * c.coutp * sizeof(double)); op.wo_stat = WS(part_off); }
+      op.grid = dim3(blocks, B, 1);
+      push(op);
+      if (a.want_stats) {
+        Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
+        memset(&f.fp, 0, sizeof f.fp);
+        f.fp.tiles = blocks; f.fp.Cs = c.coutp; f.fp.C = h->padc(c.cout);
+        f.fp.ld = a.stats_out->ld; f.fp.off = (int)a.stats_choff;
+        f.fp.inv_count = 1.0f / ((float)Hout * (float)Wout); f.fp.eps = 1e-5f;
+        f.f_part = WS(part_off);
+        if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
+        f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
+        f.grid = dim3(c.coutp / 16, B, 1);
+        finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, blocks, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
+      }
     }
     return true;
   }
@@ -948,7 +1048,8 @@ struct Builder {
                    &op.m_shift, &op.ys0, &op.ys1, &op.slab, &op.x2, &op.w2, &op.m_part,
                    &op.s_slab, &op.s_bias, &op.s_y, &op.s_res, &op.s_stat, &op.m_slab, &op.m_bias, &op.m_xm, &op.m_sc, &op.m_sh,
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
-                   &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst};
+                   &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst,
+                   &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat};
     for (PRef* r : all) if (r->sp == PS_WS) f(*r);
   }
   AllocRec* alloc_of(size_t voff) {
@@ -1387,6 +1488,18 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         if (bf16) hipLaunchKernelGGL(k_in_add<true>, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_in_add<false>, op.grid, dim3(256), 0, st, p);
       } break;
+      case OP_WINO_IN: {
+        WinoInParams p = op.wi;
+        p.x = R.get<const float>(op.wi_x); p.pro_scale = R.get<const float>(op.wi_sc); p.pro_shift = R.get<const float>(op.wi_sh);
+        p.v = R.get<float>(op.wi_v);
+        hipLaunchKernelGGL(k_wino_in, op.grid, dim3(256), 0, st, p);
+      } break;
+      case OP_WINO_OUT: {
+        WinoOutParams p = op.wo;
+        p.m = R.get<const float>(op.wo_m); p.bias = R.get<const float>(op.wo_bias); p.y = R.get<float>(op.wo_y);
+        p.res = R.get<const float>(op.wo_res); p.stat_part = R.get<double>(op.wo_stat);
+        hipLaunchKernelGGL(k_wino_out, op.grid, dim3(256), 0, st, p);
+      } break;
       case OP_PACK: {
         PackParams p = op.kp;
         p.s0 = R.get<const float>(op.k_s0); p.s1 = R.get<const float>(op.k_s1); p.s2 = R.get<const float>(op.k_s2);
@@ -1597,6 +1710,22 @@ int rib_finalize_weights(rib_handle* h) {
         blob[sg.b_off + colb] = b[sg.C + ch];
       }
     }
+  }
+  for (auto& c : h->convs) {
+    if (!c.used || !c.wu_off) continue;
+    // U[xi = 4r + q] = (G g G^T)[r][q] with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], from the folded filters
+    // (g[dy][dx] = w[o][dy*3+dx][i]); computed in fp64, stored fp32
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int o = 0; o < c.cout; ++o)
+      for (int i = 0; i < c.cin; ++i) {
+        double g[3][3], t[4][3];
+        for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = blob[c.w_off + ((size_t)o * 9 + k) * c.cinp + i];
+        for (int r = 0; r < 4; ++r)
+          for (int dx = 0; dx < 3; ++dx) t[r][dx] = G[r][0] * g[0][dx] + G[r][1] * g[1][dx] + G[r][2] * g[2][dx];
+        for (int r = 0; r < 4; ++r)
+          for (int q = 0; q < 4; ++q)
+            blob[c.wu_off + ((size_t)(r * 4 + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
+      }
   }
   if (h->mc16()) {
     // rows of `rowlen` K-contiguous elements: bf16 -> [row][rowlen]; f32x3 -> [row][plane][rowlen] with
@@ -2007,8 +2136,9 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|%s 16x16 tile, %d output channels%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
   else if (op.kind == OP_IGEMM)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB, op.flops);
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
+             op.wino ? " wino" : "", op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;

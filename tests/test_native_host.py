@@ -167,7 +167,8 @@ def test_precision_mode_switch_refolds_the_weights(lib):
             assert np.abs(w - w_ref.numpy()).max() <= 2e-6 * float(w_ref.abs().max()), (mode, cname)
         for (B, H, W) in ((1, 64, 64), (2, 48, 80), (1, 16, 16)):
             assert lib.rib_workspace_bytes(h, B, H, W) > 0, (mode, lib.rib_last_error(h))
-    assert sizes[0] == n32 and sizes[1] > 1.4 * n32 and sizes[2] > sizes[1]       # + bf16 copies / + three-plane copies
+    # (fp32 carries the Winograd-domain filters of the deep 3x3 layers; bf16 / f32x3 carry bf16 / three-plane copies instead)
+    assert sizes[0] == n32 and sizes[1] != n32 and sizes[2] > sizes[1]
     assert lib.rib_set_compute_dtype(h, 7) != 0
     lib.rib_destroy(h)
 
