@@ -535,7 +535,9 @@ void assign_weight_layout(rib_handle* h) {
     // 3x3 stride-1 convolutions with >= 128 input channels that own their launch (no fused 1x1 shortcut, no upsampled
     // input): the deep residual blocks of the generator and of the mask network
     for (auto& c : h->convs) {
-      if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 128 || c.cout < 64 || c.cinp % 32 || 256 % (c.coutp / 4)) continue;
+      // (measured per layer at 512x512, transforms included: 512->512 at 32x32 58 -> 38 us, 256->256 at 64x64 47-52 -> 42 us,
+      // 512->256 at 64x64 95 -> 63 us; 128->128 at 64x64 gains nothing: the two transforms cost ~13 us per layer)
+      if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 256 % (c.coutp / 4)) continue;
       c.wu_off = take((size_t)16 * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
     }
