@@ -710,3 +710,38 @@ def test_driver_lanes_follow_a_weight_reload(tmp_path):
         assert np.array_equal(xb, np.asarray(Image.open(fc))), fb      # every segment rendered with the NEW weights
         differs += not np.array_equal(xb, np.asarray(Image.open(fa)))
     assert differs >= 3                                                # and the new weights do change the generated frames
+
+
+def test_winograd_path_agrees_with_the_direct_convolutions(monkeypatch):
+    """The deep 3x3 layers (>= 256 input channels, maps <= 64x64) run as Winograd F(2x2, 3x3): k_wino_in, one 16-way
+    batched 1x1 k_igemm, k_wino_out with the fused epilogue (residual, activation, statistics).  With RIB_NO_WINO they
+    run as direct implicit GEMMs.  Same frame either way to fp32 summation-order tolerance - at odd map sizes too
+    (a 3x5 deepest map: partial 2x2 output tiles), with a batch, and per tap against the oracle."""
+    spec, sd, _ = build("full", 0)
+    R = oracle(spec, sd)
+    for (B, H, W, seed) in ((1, 64, 64, 1), (2, 48, 80, 2), (1, 256, 256, 3), (1, 176, 112, 4)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        monkeypatch.delenv("RIB_NO_WINO", raising=False)
+        G1 = rib.Generator(rib.hsm_gen_config()).eval(); G1.load_state_dict(sd)
+        names = [o["name"] for o in G1.launch_info(B, H, W)]
+        assert any(n.endswith(".wino") for n in names) and any(n.endswith(".wino_in") for n in names), (B, H, W)
+        if (H, W) == (64, 64):
+            G1.enable_taps()
+        i1, m1 = [t.clone() for t in G1(label, None, fake, prev)]
+        if (H, W) == (64, 64):
+            taps = G1.read_taps(B, H, W)
+            otaps = {}
+            R(label, None, fake, prev, taps=otaps)
+            for k, v in taps.items():
+                assert float((v - otaps[k]).abs().max()) / max(1.0, float(otaps[k].abs().max())) <= TOL, k
+        monkeypatch.setenv("RIB_NO_WINO", "1")
+        G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
+        assert not any(".wino" in o["name"] for o in G2.launch_info(B, H, W))
+        i2, m2 = G2(label, None, fake, prev)
+        torch.cuda.synchronize()
+        e = max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max()))
+        assert e < 5e-5, (B, H, W, e)
+        oi, om = R(label, None, fake, prev)
+        assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL, (B, H, W)
+        del G1, G2
+    monkeypatch.delenv("RIB_NO_WINO", raising=False)
