@@ -693,7 +693,9 @@ struct Builder {
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
     {
       // Winograd F(2x2, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h)
-      static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 4096;
+      // maps up to 128x128 (1024x1024 frames: +3.5 % at batch 1 and 4); beyond that V and M (4x the activation each)
+      // leave the caches and the direct kernel, which fills the chip there, was not beaten
+      static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
       if (h->prec() == PREC_F32 && c.wu_off && !a.ups && !a.aux && !a.res_ups && a.y_nchw.sp == PS_NULL && a.y_user.sp == PS_NULL &&
           (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2)
         return conv_wino(a, opname, Hout, Wout);
