@@ -1357,57 +1357,54 @@ struct WinoInParams {
 };
 
 __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
+  // thread = (tile, 4 channels, row r of the transformed tile): these maps are small (256 .. 4096 tiles), a thread per
+  // whole tile left half of the chip idle and the kernel on its load latency; a row needs two input rows (8 loads)
   const int c4n = p.Cin / 4;
   const int n = blockIdx.y;
   const int ntiles = p.tilesY * p.tilesX;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n; i += gridDim.x * 256) {
-    const int c4 = i % c4n, tile = i / c4n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n * 4; i += gridDim.x * 256) {
+    const int c4 = i % c4n, r = (i / c4n) & 3, tile = i / (c4n * 4);
     const int ty = tile / p.tilesX, tx = tile % p.tilesX;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.pro_scale) {
       sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
       sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
     }
-    float4 d[4][4];
+    // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: row r of B^T d is d[ia] + sg * d[ib]
+    const int ia = r == 0 ? 0 : (r == 2 ? 2 : 1), ib = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+    const float sg = r == 1 ? 1.f : -1.f;
+    float4 d[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+        const int iy = 2 * ty - 1 + (a ? ib : ia), ix = 2 * tx - 1 + q;
         const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        d[r][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
+        d[a][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
       }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
-        float4 v = d[r][q];
-        if (p.pro_scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
-        if (p.pro_lrelu) v = lrelu4(v);
-        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
-        d[r][q] = v;
-      }
-    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
-    float4 t[4][4];
-#define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
-#define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
+    float4 t[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      t[0][q] = RIB_F4_SUB(d[0][q], d[2][q]);
-      t[1][q] = RIB_F4_ADD(d[1][q], d[2][q]);
-      t[2][q] = RIB_F4_SUB(d[2][q], d[1][q]);
-      t[3][q] = RIB_F4_SUB(d[1][q], d[3][q]);
+      float4 v[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int iy = 2 * ty - 1 + (a ? ib : ia), ix = 2 * tx - 1 + q;
+        float4 w = d[a][q];
+        if (p.pro_scale) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
+        if (p.pro_lrelu) w = lrelu4(w);
+        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+        v[a] = w;
+      }
+      t[q] = make_float4(v[0].x + sg * v[1].x, v[0].y + sg * v[1].y, v[0].z + sg * v[1].z, v[0].w + sg * v[1].w);
     }
+#define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
+#define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
     const size_t plane = (size_t)ntiles * p.Cin;              // one position's [tiles][Cin] matrix
     float* vb = p.v + (size_t)n * 16 * plane + (size_t)tile * p.Cin + c4 * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 0) * plane) = RIB_F4_SUB(t[r][0], t[r][2]);
-      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 1) * plane) = RIB_F4_ADD(t[r][1], t[r][2]);
-      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 2) * plane) = RIB_F4_SUB(t[r][2], t[r][1]);
-      *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 3) * plane) = RIB_F4_SUB(t[r][1], t[r][3]);
-    }
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 0) * plane) = RIB_F4_SUB(t[0], t[2]);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 1) * plane) = RIB_F4_ADD(t[1], t[2]);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 2) * plane) = RIB_F4_SUB(t[2], t[1]);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 3) * plane) = RIB_F4_SUB(t[1], t[3]);
   }
 }
 
@@ -1420,65 +1417,60 @@ struct WinoOutParams {
   double* stat_part; int blocks;                  // [B][blocks][2][CoutPad]
 };
 
-// grid (blocks, B); thread = (tile slot, 4 channels); a block covers 256 / (CoutPad/4) tiles
+// grid (blocks, B); thread = (tile slot, output row r of the 2x2 tile, 4 channels); a block covers 128 / (CoutPad/4) tiles
 __global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
   __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.CoutPad / 4;
-  const int slots = 256 / c4n;
-  const int c4 = threadIdx.x % c4n, slot = threadIdx.x / c4n;
+  const int slots2 = 256 / c4n;                  // (tile, row) pairs per block
+  const int c4 = threadIdx.x % c4n, sr = threadIdx.x / c4n;
+  const int r = sr & 1, slot = sr >> 1;
   const int n = blockIdx.y;
   const int ntiles = p.tilesY * p.tilesX;
-  const int tile = blockIdx.x * slots + slot;
+  const int tile = blockIdx.x * (slots2 / 2) + slot;
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  if (tile < ntiles && slot < slots) {
+  if (tile < ntiles && sr < slots2) {
     const size_t plane = (size_t)ntiles * p.CoutPad;
     const float* mb = p.m + (size_t)n * 16 * plane + (size_t)tile * p.CoutPad + c4 * 4;
-    float4 mm[4][4];
+    // A^T = [1 1 1 0; 0 1 -1 -1]: output row r combines the rows r, r+1, r+2 of M: (+, +, +) for r = 0, (+, -, -) for r = 1
+    float4 mm[3][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mm[r][q] = *reinterpret_cast<const float4*>(mb + (size_t)(r * 4 + q) * plane);
-    // A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]
-    float4 u[2][4];
+      for (int q = 0; q < 4; ++q) mm[a][q] = *reinterpret_cast<const float4*>(mb + (size_t)((r + a) * 4 + q) * plane);
+    const float sg = r ? -1.f : 1.f;
+    float4 u[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      u[0][q] = RIB_F4_ADD(RIB_F4_ADD(mm[0][q], mm[1][q]), mm[2][q]);
-      u[1][q] = RIB_F4_SUB(RIB_F4_SUB(mm[1][q], mm[2][q]), mm[3][q]);
-    }
-    float4 yv[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      yv[r][0] = RIB_F4_ADD(RIB_F4_ADD(u[r][0], u[r][1]), u[r][2]);
-      yv[r][1] = RIB_F4_SUB(RIB_F4_SUB(u[r][1], u[r][2]), u[r][3]);
-    }
+    for (int q = 0; q < 4; ++q)
+      u[q] = make_float4(mm[0][q].x + sg * (mm[1][q].x + mm[2][q].x), mm[0][q].y + sg * (mm[1][q].y + mm[2][q].y),
+                         mm[0][q].z + sg * (mm[1][q].z + mm[2][q].z), mm[0][q].w + sg * (mm[1][q].w + mm[2][q].w));
+    float4 yv[2];
+    yv[0] = RIB_F4_ADD(RIB_F4_ADD(u[0], u[1]), u[2]);
+    yv[1] = RIB_F4_SUB(RIB_F4_SUB(u[1], u[2]), u[3]);
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
     const int ty = tile / p.tilesX, tx = tile % p.tilesX;
-    float rr[2][2][4];
+    const int oy = 2 * ty + r;
+    float rr[2][4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int q = 0; q < 2; ++q) {
+      const int cy = min(oy, p.Hout - 1), cx = min(2 * tx + q, p.Wout - 1);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int oy = min(2 * ty + r, p.Hout - 1), ox = min(2 * tx + q, p.Wout - 1);
+      for (int e = 0; e < 4; ++e)
+        rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          rr[r][q][e] = p.res ? p.res[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+    for (int q = 0; q < 2; ++q) {
+      const int ox = 2 * tx + q;
+      const bool inb = oy < p.Hout && ox < p.Wout;
+      const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = apply_act(v4[e] + rr[q][e], p.act);
+        const bool ok = inb && c4 * 4 + e < p.Cout;
+        if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
+        t = ok ? t : 0.f;
+        s1[e] += (double)t; s2[e] += (double)t * (double)t;
       }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int oy = 2 * ty + r, ox = 2 * tx + q;
-        const bool inb = oy < p.Hout && ox < p.Wout;
-        const float v4[4] = {yv[r][q].x + bv.x, yv[r][q].y + bv.y, yv[r][q].z + bv.z, yv[r][q].w + bv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = apply_act(v4[e] + rr[r][q][e], p.act);
-          const bool ok = inb && c4 * 4 + e < p.Cout;
-          if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
-          t = ok ? t : 0.f;
-          s1[e] += (double)t; s2[e] += (double)t * (double)t;
-        }
-      }
+    }
   }
   if (p.stat_part) {
 #pragma unroll
@@ -1487,7 +1479,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
     for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
       const int g = c / 4, e = c % 4;
       double a1 = 0.0, a2 = 0.0;
-      for (int s = 0; s < slots; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
+      for (int s = 0; s < slots2; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
       double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
       dst[c] = a1;
       dst[p.CoutPad + c] = a2;

@@ -537,7 +537,7 @@ void assign_weight_layout(rib_handle* h) {
     for (auto& c : h->convs) {
       // (measured per layer at 512x512, transforms included: 512->512 at 32x32 58 -> 38 us, 256->256 at 64x64 47-52 -> 42 us,
       // 512->256 at 64x64 95 -> 63 us; 128->128 at 64x64 gains nothing: the two transforms cost ~13 us per layer)
-      if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 256 % (c.coutp / 4)) continue;
+      if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 128 % (c.coutp / 4)) continue;
       c.wu_off = take((size_t)16 * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
     }
@@ -840,8 +840,8 @@ struct Builder {
         op.wi.pro_ld = a.pro->ld;
         op.wi_sc = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.wi_sh = WS(a.pro->sh + a.pro_choff * sizeof(float));
       }
-      const size_t total = (size_t)ntiles * (c.cinp / 4);
-      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096), B, 1);
+      const size_t total = (size_t)ntiles * (c.cinp / 4) * 4;      // thread = (tile, 4 channels, transformed row)
+      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192), B, 1);
       push(op);
     }
     {   // the 16 GEMMs as one 1x1 "convolution" of 16*B samples of a tilesY x tilesX image, one filter set per position
@@ -872,7 +872,7 @@ struct Builder {
     {   // output transform + the convolution's epilogue
       Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_out"; op.for_op = gname;
       memset(&op.wo, 0, sizeof op.wo);
-      const int slots = 256 / (c.coutp / 4), blocks = (ntiles + slots - 1) / slots;
+      const int slots = 128 / (c.coutp / 4), blocks = (ntiles + slots - 1) / slots;      // thread = (tile, output row, 4 channels)
       op.wo.tilesY = tilesY; op.wo.tilesX = tilesX; op.wo.CoutPad = c.coutp; op.wo.blocks = blocks;
       op.wo.yC = a.out.Cp; op.wo.yoff = a.yoff; op.wo.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
       op.wo.Hout = Hout; op.wo.Wout = Wout; op.wo.act = a.act;
