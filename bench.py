@@ -260,7 +260,8 @@ def main():
         "bound": "mfma",
         # the convolution class: k_igemm on the matrix cores; at fp32 the 1..4-channel heads (conv_img, conv_mask.0:
         # 2 launches, 0.5 GFLOP) run as k_conv_small on the vector ALUs.  "algorithmic" = nine-tap 2*MAC count of
-        # SURVEY 8(d); the three upsample convolutions execute 4/9 of theirs (phase decomposition)
+        # SURVEY 8(d); the three upsample convolutions (phase decomposition) and the Winograd-domain GEMMs of the deep 3x3
+        # layers execute 4/9 of theirs: `executed_*` below counts what the matrix cores actually do
         "kernel": "convolution class: k_igemm, %s MFMA implicit GEMM (%d launches/step incl. 2 k_conv_small heads)" % (args.dtype, int(prof["igemm"]["launches"] / nprof)),
         "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
         "frac": conv_tflops / peak,
