@@ -234,7 +234,8 @@ def main():
     executed = 0.0
     for info in G.launch_info(B, H, W):
         if info["class"] == 0:
-            executed += info["flops"] * (4.0 / 9.0 if ("ups1" in info["tile"] or "wino" in info["tile"]) else 1.0)
+            tile = info["tile"]
+            executed += info["flops"] * (0.25 if "wino4" in tile else 4.0 / 9.0 if ("ups1" in tile or "wino" in tile) else 1.0)
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py:
     # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc passes); bench.py itself cannot read counters,
     # so this is a pointer to the committed measurement of the same workload, NOT measured in this run

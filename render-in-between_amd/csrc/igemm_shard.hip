@@ -61,6 +61,8 @@
 #define RIB_VB(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VB(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VBX(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VBX(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VX3(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VX3(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_V1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_V1D(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VS1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VS1D(RIB_F_TOUCH, __VA_ARGS__))
 
 typedef void (*IgemmFn)(const rib::IgemmParams);
 extern "C" __attribute__((used, visibility("hidden"))) IgemmFn const RIB_CAT(rib_igemm_section_, RIB_SECTION)[] = {

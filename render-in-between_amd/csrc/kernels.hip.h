@@ -233,8 +233,10 @@ struct IgemmGeom {
   static constexpr int NB4 = (BN * GPRB + NT - 1) / NT;    // 16-byte filter loads per thread per tap
   static constexpr int SRED = WM * BN * 4;     // floats: [WM][BN][2] fp64 statistics partials
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
-  static constexpr int NA = TB == 9 ? 2 : 1;   // TB = 9 also double-buffers the input tile: one barrier per chunk
-  static constexpr int SMEM0 = NA * SA + 2 * TB * SB > SRED ? NA * SA + 2 * TB * SB : SRED;
+  // TB = 9 (3x3) and TB = 2 (1x1: "chunk pairs") also double-buffer the input tile: one barrier per chunk
+  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2)) ? 2 : 1;
+  static constexpr int TBB = (KS == 1 && TB == 2) ? 1 : TB;   // filter slices per buffer
+  static constexpr int SMEM0 = NA * SA + 2 * TBB * SB > SRED ? NA * SA + 2 * TBB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
   static constexpr int TAPS = UPS ? 16 : KS * KS;   // filter slices per channel chunk (row stride of w)
 };
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
   constexpr int WSZ = (BF16 || X3) ? 2 : 4;     // bytes per stored filter element
   constexpr int EPS = G::EPS, GPR = G::GPR, GPRB = G::GPRB;
   constexpr int EPB = 16 / WSZ;                 // filter elements per 16-byte slot
-  static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS),
+  static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS) || (TB == 2 && KS == 1 && !UPS && STRIDE == 1),
                 "filter slices per barrier: one tap, one row of a 3x3 filter, all nine; phase convolutions: the four taps of a phase");
   constexpr int NT = G::NT;
   static_assert(KW == 1 || (NF > 0 && (BK / ((BF16 || X3) ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
 
   // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
   // filter slice / input chunk are in flight while the current one feeds the matrix cores ----
-  float4 breg[G::NB4 * TB];
+  float4 breg[G::NB4 * G::TBB];
   auto loadB = [&](int kc, int tap) {
 #pragma unroll
     for (int i = 0; i < G::NB4; ++i) {
@@ -712,6 +714,26 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       }
 #endif
     }
+  } else if constexpr (KS == 1 && TB == 2) {
+    // 1x1 with input tile AND filter slice double-buffered: ONE barrier per channel chunk instead of two (a 1x1 chunk is
+    // a single "tap" of 16-32 MFMAs per wave, so the barriers weigh far more than in a nine-tap 3x3 chunk): chunk k+1
+    // is written to the other buffers right after the MFMAs of chunk k - its global loads were in flight during them
+    loadB(kc_begin, 0);
+    prefetchA(kc_begin);
+    consumer_stats();
+    writeA(false);
+    storeB(0);
+    int stage = 0;
+    for (int kc = kc_begin; kc < kc_end; kc += BK, ++stage) {
+      const int buf = stage & 1;
+      const bool more = kc + BK < kc_end;
+      if (more) { loadB(kc + BK, 0); prefetchA(kc + BK); }
+      __syncthreads();
+      sA = smem + buf * G::SA;
+      compute_tap(0, 0, buf);
+      if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB(buf ^ 1); }
+    }
+    sA = smem;
   } else if constexpr (TB == 9) {
     // all nine filter slices of a chunk staged at once; input tile AND filters double-buffered across chunks, so a
     // chunk costs ONE barrier: chunk k+1 is written to the other buffers right after the MFMAs of chunk k (its
@@ -1488,6 +1510,168 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
 }
 #undef RIB_F4_SUB
 #undef RIB_F4_ADD
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3): 36 positions, 4x4 outputs per tile, 1/4 of the nine-tap multiplications (F(2x2): 4/9) and 2.25
+// transformed values per activation instead of 4.  Interpolation points {0, +-3/4, +-3/2, inf} instead of the textbook
+// {0, +-1, +-2}: every entry of B^T and A^T stays dyadic (exact in fp32) and the fp32 error of a 256-channel layer is
+// 9e-6 max / 1.4e-6 rms on O(4) outputs against 4.9e-5 / 2.9e-6 for the textbook points, 2.7e-6 / 4.6e-7 for F(2x2) and
+// 1.4e-6 for the direct fp32 convolution (numpy model of the three stages, tools/probes/wino_points.py).  G (thirds) is
+// folded into U on the host in fp64.  Same three launches and layouts as F(2x2) with 36 in place of 16:
+// V [B*36][tilesY][tilesX][Cin], M [B*36][tilesY][tilesX][CoutPad], sample = n*36 + 6*row + col, tile origin (4ty-1, 4tx-1).
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ float kWino4BT[6][6] = {
+    {81.f / 64, 0.f, -45.f / 16, 0.f, 1.f, 0.f},        {0.f, -27.f / 16, -9.f / 4, 3.f / 4, 1.f, 0.f},
+    {0.f, 27.f / 16, -9.f / 4, -3.f / 4, 1.f, 0.f},     {0.f, -27.f / 32, -9.f / 16, 3.f / 2, 1.f, 0.f},
+    {0.f, 27.f / 32, -9.f / 16, -3.f / 2, 1.f, 0.f},    {0.f, 81.f / 64, 0.f, -45.f / 16, 0.f, 1.f}};
+__device__ __constant__ float kWino4AT[4][6] = {
+    {1.f, 1.f, 1.f, 1.f, 1.f, 0.f},                      {0.f, 3.f / 4, -3.f / 4, 3.f / 2, -3.f / 2, 0.f},
+    {0.f, 9.f / 16, 9.f / 16, 9.f / 4, 9.f / 4, 0.f},    {0.f, 27.f / 64, -27.f / 64, 27.f / 8, -27.f / 8, 1.f}};
+
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc) {
+  return make_float4(fmaf(a, x.x, acc.x), fmaf(a, x.y, acc.y), fmaf(a, x.z, acc.z), fmaf(a, x.w, acc.w));
+}
+__device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
+
+// thread = (tile, transformed row r, 4 channels); row r of B^T d needs the 3 or 4 input rows with a non-zero coefficient
+__global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
+  const int c4n = p.Cin / 4;
+  const int n = blockIdx.y;
+  const int ntiles = p.tilesY * p.tilesX;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n * 6; i += gridDim.x * 256) {
+    const int c4 = i % c4n, r = (i / c4n) % 6, tile = i / (c4n * 6);
+    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pro_scale) {
+      sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+      sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+    }
+    // rows with a non-zero coefficient: r = 0 -> {0, 2, 4}; r = 1..4 -> {1, 2, 3, 4}; r = 5 -> {1, 3, 5}
+    const int a0 = r == 0 ? 0 : 1, da = (r == 0 || r == 5) ? 2 : 1, na = (r == 0 || r == 5) ? 3 : 4;
+    float4 d[4][6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int iy = 4 * ty - 1 + a0 + min(k, na - 1) * da, ix = 4 * tx - 1 + q;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        d[k][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
+      }
+    float4 t[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) t[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = a0 + min(k, na - 1) * da;
+      const float coef = k < na ? kWino4BT[r][a] : 0.f;
+      const int iy = 4 * ty - 1 + a;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int ix = 4 * tx - 1 + q;
+        float4 w = d[k][q];
+        if (p.pro_scale) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
+        if (p.pro_lrelu) w = lrelu4(w);
+        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+        t[q] = f4_fma(coef, w, t[q]);
+      }
+    }
+    const size_t plane = (size_t)ntiles * p.Cin;
+    float* vb = p.v + (size_t)n * 36 * plane + (size_t)tile * p.Cin + c4 * 4;
+    // columns: V[r][j] = sum_q B^T[j][q] t[q] (compile-time coefficients)
+    const float4 e24 = f4_fma(-45.f / 16, t[2], t[4]);                 // -45/16 t2 + t4
+    const float4 o13 = f4_fma(-45.f / 16, t[3], t[5]);                 // -45/16 t3 + t5
+    const float4 ev1 = f4_fma(-9.f / 4, t[2], t[4]), od1 = f4_fma(-27.f / 16, t[1], f4_scale(3.f / 4, t[3]));
+    const float4 ev2 = f4_fma(-9.f / 16, t[2], t[4]), od2 = f4_fma(-27.f / 32, t[1], f4_scale(3.f / 2, t[3]));
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 0) * plane) = f4_fma(81.f / 64, t[0], e24);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 1) * plane) = make_float4(ev1.x + od1.x, ev1.y + od1.y, ev1.z + od1.z, ev1.w + od1.w);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 2) * plane) = make_float4(ev1.x - od1.x, ev1.y - od1.y, ev1.z - od1.z, ev1.w - od1.w);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 3) * plane) = make_float4(ev2.x + od2.x, ev2.y + od2.y, ev2.z + od2.z, ev2.w + od2.w);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 4) * plane) = make_float4(ev2.x - od2.x, ev2.y - od2.y, ev2.z - od2.z, ev2.w - od2.w);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 5) * plane) = f4_fma(81.f / 64, t[1], o13);
+  }
+}
+
+// grid (blocks, B); thread = ((tile, output row r of the 4x4 tile), 4 channels); a block covers 256 / (CoutPad/4) such rows
+__global__ __launch_bounds__(256) void k_wino4_out(const WinoOutParams p) {
+  __shared__ __attribute__((aligned(16))) double red[2][256][4];
+  const int c4n = p.CoutPad / 4;
+  const int upb = 256 / c4n;                     // (tile, row) units per block
+  const int c4 = threadIdx.x % c4n, us = threadIdx.x / c4n;
+  const int n = blockIdx.y;
+  const int ntiles = p.tilesY * p.tilesX;
+  const int unit = blockIdx.x * upb + us;
+  const int tile = unit >> 2, r = unit & 3;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tile < ntiles) {
+    const size_t plane = (size_t)ntiles * p.CoutPad;
+    const float* mb = p.m + (size_t)n * 36 * plane + (size_t)tile * p.CoutPad + c4 * 4;
+    // u[q] = sum_a A^T[r][a] M[a][q]: rows 1..4 always, row 0 for r = 0, row 5 for r = 3
+    float4 u[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) u[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ax = r == 0 ? 0 : 5;               // the extra row (coefficient 1 for r = 0 / 3, unused otherwise)
+    const float cx_ = (r == 0 || r == 3) ? 1.f : 0.f;
+    float4 mm[5][6];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) mm[k][q] = *reinterpret_cast<const float4*>(mb + (size_t)((k < 4 ? k + 1 : ax) * 6 + q) * plane);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float coef = k < 4 ? kWino4AT[r][k + 1] : cx_;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) u[q] = f4_fma(coef, mm[k][q], u[q]);
+    }
+    // y[j] = sum_q A^T[j][q] u[q]
+    const float4 s12 = make_float4(u[1].x + u[2].x, u[1].y + u[2].y, u[1].z + u[2].z, u[1].w + u[2].w);
+    const float4 d12 = make_float4(u[1].x - u[2].x, u[1].y - u[2].y, u[1].z - u[2].z, u[1].w - u[2].w);
+    const float4 s34 = make_float4(u[3].x + u[4].x, u[3].y + u[4].y, u[3].z + u[4].z, u[3].w + u[4].w);
+    const float4 d34 = make_float4(u[3].x - u[4].x, u[3].y - u[4].y, u[3].z - u[4].z, u[3].w - u[4].w);
+    float4 yv[4];
+    yv[0] = make_float4(u[0].x + s12.x + s34.x, u[0].y + s12.y + s34.y, u[0].z + s12.z + s34.z, u[0].w + s12.w + s34.w);
+    yv[1] = f4_fma(3.f / 4, d12, f4_scale(3.f / 2, d34));
+    yv[2] = f4_fma(9.f / 16, s12, f4_scale(9.f / 4, s34));
+    yv[3] = f4_fma(27.f / 64, d12, f4_fma(27.f / 8, d34, u[5]));
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+    const int oy = 4 * ty + r;
+    float rr[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cy = min(oy, p.Hout - 1), cx = min(4 * tx + q, p.Wout - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ox = 4 * tx + q;
+      const bool inb = oy < p.Hout && ox < p.Wout;
+      const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = apply_act(v4[e] + rr[q][e], p.act);
+        const bool ok = inb && c4 * 4 + e < p.Cout;
+        if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
+        t = ok ? t : 0.f;
+        s1[e] += (double)t; s2[e] += (double)t * (double)t;
+      }
+    }
+  }
+  if (p.stat_part) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
+      const int g = c / 4, e = c % 4;
+      double a1 = 0.0, a2 = 0.0;
+      for (int s = 0; s < upb; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
+      double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
+      dst[c] = a1;
+      dst[p.CoutPad + c] = a2;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_spade_modulate: second half of an UNFUSED SPADE (used where the map is small and the fused

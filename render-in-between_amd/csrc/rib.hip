@@ -39,6 +39,8 @@
 #define RIB_VB(sec, ...) RIB_I_VB(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VBX(sec, ...) RIB_I_VBX(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VX3(sec, ...) RIB_I_VX3(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_V1D(sec, ...) RIB_I_V1D(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VS1D(sec, ...) RIB_I_VS1D(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
 #undef RIB_V
 #undef RIB_VK
@@ -51,6 +53,8 @@
 #undef RIB_VB
 #undef RIB_VBX
 #undef RIB_VX3
+#undef RIB_V1D
+#undef RIB_VS1D
 
 using namespace rib;
 
@@ -106,6 +110,7 @@ struct ConvDef {
   // Winograd F(2x2, 3x3) filters U = G g G^T, [16 positions][CoutPad][CinPad] fp32, and a zero bias vector for the
   // batched GEMM (the real bias is added by the output transform); 0: the layer never runs that way
   size_t wu_off = 0, zero_off = 0;
+  int wino_m = 0;      // Winograd output tile (2: F(2x2,3x3), 16 positions; 4: F(4x4,3x3), 36 positions) when wu_off != 0
 };
 
 struct TensorDef {
@@ -208,7 +213,8 @@ struct Variant {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
     const int ck = (BF16 == PREC_BF16 ? BK / 2 : (BF16 == PREC_F32X3 ? 3 * BK / 2 : BK)) + 4;   // IgemmGeom::CK
-    const int main_loop = ((TB == 9 ? 2 : 1) * ih * iwp * ck + 2 * TB * BN() * ck) * 4;   // IgemmGeom::NA
+    const bool db1 = KS == 1 && TB == 2;                                                        // 1x1, everything double-buffered
+    const int main_loop = (((TB == 9 || db1) ? 2 : 1) * ih * iwp * ck + 2 * (db1 ? 1 : TB) * BN() * ck) * 4;   // IgemmGeom::NA, TBB
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
     return main_loop > kw_reduce ? main_loop : kw_reduce;
   }
@@ -259,6 +265,14 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW},
 #define RIB_VB(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true},
+// 1x1, everything double-buffered (TB = 2): convolution (pro / lean) and SPADE
+#define RIB_V1D(sec, FRW, WM, WN, MF, NF, BK, KW)                                                                    \
+  Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, false,                                                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2>, 0,                            \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2>,                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, false, KW, 2>, KW, 2},
+#define RIB_VS1D(sec, FRW, WM, WN, MF, NF, BK, KW) \
+  Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, true, true, KW, 2>, 0, nullptr, nullptr, KW, 2},
 #define RIB_VX3(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 2, nullptr, nullptr, KW, TB},
@@ -325,7 +339,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
       // in-workgroup split-K: KW wave groups interleave on the same SIMDs, which hides 1/KW more of the
       // overheads; the accumulator hand-over costs two barriers and 16 KB of LDS traffic per extra group
-      const double ovh_wg = (chunks * (taps / v.TB * 350.0 + 600.0) + 7000.0) / v.KW + (v.KW - 1) * 1500.0;
+      const double ovh_wg = (chunks * (std::max(1, taps / v.TB) * 350.0 + (ks == 1 && v.TB == 2 ? 300.0 : 600.0)) + 7000.0) / v.KW + (v.KW - 1) * 1500.0;
       const double mfma_wg = (double)chunks * taps * mfma_tap;
       const double t_lat = std::ceil((double)wgs / (256.0 * occ)) * (mfma_wg + ovh_wg);
       const double t_cu = std::ceil((double)wgs / 256.0) * (mfma_wg + ovh_wg / occ);
@@ -392,7 +406,8 @@ struct Op {
   // Winograd transforms
   WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v;
   WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
-  bool wino = false;   // this k_igemm launch is the 16-way batched Winograd-domain GEMM (executes 4/9 of its nine-tap FLOP count)
+  bool wino = false;   // this k_igemm launch is the 16- / 36-way batched Winograd-domain GEMM (executes 4/9 or 1/4 of its nine-tap FLOP count)
+  int wino_m = 0;      // 2 or 4 on the three launches of a Winograd convolution
 };
 
 struct PendingStats {
@@ -530,7 +545,7 @@ void assign_weight_layout(rib_handle* h) {
     h->spade_index[sg.key] = (int)h->spades.size();
     h->spades.push_back(sg);
   }
-  for (auto& c : h->convs) { c.wu_off = 0; c.zero_off = 0; }
+  for (auto& c : h->convs) { c.wu_off = 0; c.zero_off = 0; c.wino_m = 0; }
   if (h->prec() == PREC_F32 && !getenv("RIB_NO_WINO")) {
     // 3x3 stride-1 convolutions with >= 128 input channels that own their launch (no fused 1x1 shortcut, no upsampled
     // input): the deep residual blocks of the generator and of the mask network
@@ -538,7 +553,9 @@ void assign_weight_layout(rib_handle* h) {
       // (measured per layer at 512x512, transforms included: 512->512 at 32x32 58 -> 38 us, 256->256 at 64x64 47-52 -> 42 us,
       // 512->256 at 64x64 95 -> 63 us; 128->128 at 64x64 gains nothing: the two transforms cost ~13 us per layer)
       if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 128 % (c.coutp / 4)) continue;
-      c.wu_off = take((size_t)16 * c.coutp * c.cinp);
+      // RIB_WINO_M=2: F(2x2, 3x3) (16 positions, 4/9 of the multiplications); default F(4x4, 3x3) (36 positions, 1/4)
+      c.wino_m = (getenv("RIB_WINO_M") && atoi(getenv("RIB_WINO_M")) == 2) ? 2 : 4;
+      c.wu_off = take((size_t)(c.wino_m + 2) * (c.wino_m + 2) * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
     }
   }
@@ -825,12 +842,13 @@ struct Builder {
 
   bool conv_wino(const ConvArgs& a, const std::string& opname, int Hout, int Wout) {
     const ConvDef& c = *a.cd;
-    const int tilesY = (Hout + 1) / 2, tilesX = (Wout + 1) / 2, ntiles = tilesY * tilesX;
-    const std::string gname = opname + ".wino";
-    const size_t v_off = alloc((size_t)B * 16 * ntiles * c.cinp * sizeof(float));
-    const size_t m_off = alloc((size_t)B * 16 * ntiles * c.coutp * sizeof(float));
+    const int wm = c.wino_m, NP = (wm + 2) * (wm + 2);      // output tile edge, Winograd positions
+    const int tilesY = (Hout + wm - 1) / wm, tilesX = (Wout + wm - 1) / wm, ntiles = tilesY * tilesX;
+    const std::string gname = opname + (wm == 2 ? ".wino" : ".wino4");
+    const size_t v_off = alloc((size_t)B * NP * ntiles * c.cinp * sizeof(float));
+    const size_t m_off = alloc((size_t)B * NP * ntiles * c.coutp * sizeof(float));
     {   // input transform (with the convolution's prologue)
-      Op op; op.kind = OP_WINO_IN; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_in"; op.for_op = gname;
+      Op op; op.kind = OP_WINO_IN; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_in"; op.for_op = gname; op.wino_m = wm;
       memset(&op.wi, 0, sizeof op.wi);
       op.wi.H = a.in.H; op.wi.W = a.in.W; op.wi.xC = a.in.Cp; op.wi.Cin = c.cinp; op.wi.tilesY = tilesY; op.wi.tilesX = tilesX;
       op.wi.pro_lrelu = a.pro_lrelu ? 1 : 0;
@@ -840,12 +858,12 @@ struct Builder {
         op.wi.pro_ld = a.pro->ld;
         op.wi_sc = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.wi_sh = WS(a.pro->sh + a.pro_choff * sizeof(float));
       }
-      const size_t total = (size_t)ntiles * (c.cinp / 4) * 4;      // thread = (tile, 4 channels, transformed row)
+      const size_t total = (size_t)ntiles * (c.cinp / 4) * (wm + 2);      // thread = (tile, 4 channels, transformed row)
       op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192), B, 1);
       push(op);
     }
-    {   // the 16 GEMMs as one 1x1 "convolution" of 16*B samples of a tilesY x tilesX image, one filter set per position
-      Choice ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * 16, tilesY, tilesX, c.cinp, false, 0, false);
+    {   // the 16 / 36 GEMMs as one 1x1 "convolution" of NP*B samples of a tilesY x tilesX image, one filter set per position
+      Choice ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * NP, tilesY, tilesX, c.cinp, false, 0, false);
       auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, gname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
@@ -856,23 +874,25 @@ struct Builder {
       }
       const Variant* v = ch.v;
       if (!v) { error = gname + ": no 1x1 kernel variant"; return false; }
-      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = gname; op.var = v; op.wino = true;
+      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = gname; op.var = v; op.wino = true; op.wino_m = wm;
       IgemmParams& p = op.ip;
       memset(&p, 0, sizeof p);
       p.Hin = tilesY; p.Win = tilesX; p.xC = c.cinp; p.Cin = c.cinp; p.CoutPad = c.coutp; p.Hout = tilesY; p.Wout = tilesX;
       p.tilesX = (tilesX + v->TW() - 1) / v->TW(); p.tilesY = (tilesY + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       p.act = ACT_NONE; p.ksplit = 1; p.yC = c.coutp; p.yoff = 0; p.Cout = c.coutp;
-      p.w_mod = 16; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
+      p.w_mod = NP; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
       op.x = WS(v_off); op.w = WT(c.wu_off); op.bias = WT(c.zero_off); op.y = WS(m_off);
-      op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * 16);
-      op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 of it)
+      op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * NP);
+      op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 or 1/4 of it)
       P->flops[RIB_KC_IGEMM] += op.flops;
       push(op);
     }
     {   // output transform + the convolution's epilogue
-      Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_out"; op.for_op = gname;
+      Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_out"; op.for_op = gname; op.wino_m = wm;
       memset(&op.wo, 0, sizeof op.wo);
-      const int slots = 128 / (c.coutp / 4), blocks = (ntiles + slots - 1) / slots;      // thread = (tile, output row, 4 channels)
+      // thread = (tile, output row, 4 channels): F(2x2) 128 / (coutp/4) tiles per block, F(4x4) 256 / (coutp/4) (tile, row) units
+      const int slots = 128 / (c.coutp / 4);
+      const int blocks = wm == 2 ? (ntiles + slots - 1) / slots : (ntiles * 4 + 2 * slots - 1) / (2 * slots);
       op.wo.tilesY = tilesY; op.wo.tilesX = tilesX; op.wo.CoutPad = c.coutp; op.wo.blocks = blocks;
       op.wo.yC = a.out.Cp; op.wo.yoff = a.yoff; op.wo.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
       op.wo.Hout = Hout; op.wo.Wout = Wout; op.wo.act = a.act;
@@ -1496,13 +1516,15 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         WinoInParams p = op.wi;
         p.x = R.get<const float>(op.wi_x); p.pro_scale = R.get<const float>(op.wi_sc); p.pro_shift = R.get<const float>(op.wi_sh);
         p.v = R.get<float>(op.wi_v);
-        hipLaunchKernelGGL(k_wino_in, op.grid, dim3(256), 0, st, p);
+        if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_in, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_wino_in, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_WINO_OUT: {
         WinoOutParams p = op.wo;
         p.m = R.get<const float>(op.wo_m); p.bias = R.get<const float>(op.wo_bias); p.y = R.get<float>(op.wo_y);
         p.res = R.get<const float>(op.wo_res); p.stat_part = R.get<double>(op.wo_stat);
-        hipLaunchKernelGGL(k_wino_out, op.grid, dim3(256), 0, st, p);
+        if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_out, op.grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_wino_out, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_PACK: {
         PackParams p = op.kp;
@@ -1717,18 +1739,25 @@ int rib_finalize_weights(rib_handle* h) {
   }
   for (auto& c : h->convs) {
     if (!c.used || !c.wu_off) continue;
-    // U[xi = 4r + q] = (G g G^T)[r][q] with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], from the folded filters
-    // (g[dy][dx] = w[o][dy*3+dx][i]); computed in fp64, stored fp32
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    // U[xi = T r + q] = (G g G^T)[r][q], T = m + 2, from the folded filters (g[dy][dx] = w[o][dy*3+dx][i]); fp64, stored fp32.
+    // F(2x2): G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  F(4x4): Cook-Toom with the points {0, +-3/4, +-3/2, inf}
+    // (kernels.hip.h, k_wino4_in): G[j] = (1, a_j, a_j^2) / prod_{k != j} (a_j - a_k), last row (0, 0, 1).
+    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const double G4[6][3] = {{64.0 / 81, 0, 0},
+                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},     {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                    {0, 0, 1}};
+    const int T = c.wino_m + 2;
+    const double (*G)[3] = c.wino_m == 2 ? G2 : G4;
     for (int o = 0; o < c.cout; ++o)
       for (int i = 0; i < c.cin; ++i) {
-        double g[3][3], t[4][3];
+        double g[3][3], t[6][3];
         for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = blob[c.w_off + ((size_t)o * 9 + k) * c.cinp + i];
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < T; ++r)
           for (int dx = 0; dx < 3; ++dx) t[r][dx] = G[r][0] * g[0][dx] + G[r][1] * g[1][dx] + G[r][2] * g[2][dx];
-        for (int r = 0; r < 4; ++r)
-          for (int q = 0; q < 4; ++q)
-            blob[c.wu_off + ((size_t)(r * 4 + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
+        for (int r = 0; r < T; ++r)
+          for (int q = 0; q < T; ++q)
+            blob[c.wu_off + ((size_t)(r * T + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
       }
   }
   if (h->mc16()) {
@@ -2142,7 +2171,7 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   else if (op.kind == OP_IGEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
-             op.wino ? " wino" : "", op.flops);
+             op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;

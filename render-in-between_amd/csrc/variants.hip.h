@@ -48,3 +48,8 @@
 // f32x3 variant (fp32 storage, operands split into three bf16 terms): PREC = 2
 #define RIB_I_VX3(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
   F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
+// 1x1 with input tile and filter slice double-buffered (TB = 2: one barrier per chunk), optional wave groups; conv (generic = pro, lean) and SPADE
+#define RIB_I_V1D(F, FRW, WM, WN, MF, NF, BK, KW)                                \
+  F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2)          \
+  F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, false, KW, 2)
+#define RIB_I_VS1D(F, FRW, WM, WN, MF, NF, BK, KW) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, true, true, KW, 2)
