@@ -109,8 +109,7 @@ struct ConvDef {
   size_t w16_off = 0, wp16_off = 0;
   // Winograd F(2x2, 3x3) filters U = G g G^T, [16 positions][CoutPad][CinPad] fp32, and a zero bias vector for the
   // batched GEMM (the real bias is added by the output transform); 0: the layer never runs that way
-  size_t wu_off = 0, zero_off = 0;
-  int wino_m = 0;      // Winograd output tile (2: F(2x2,3x3), 16 positions; 4: F(4x4,3x3), 36 positions) when wu_off != 0
+  size_t wu_off = 0, wu4_off = 0, zero_off = 0;   // Winograd-domain filters: F(2x2,3x3) [16][coutp][cinp], F(4x4,3x3) [36][coutp][cinp]
 };
 
 struct TensorDef {
@@ -545,7 +544,7 @@ void assign_weight_layout(rib_handle* h) {
     h->spade_index[sg.key] = (int)h->spades.size();
     h->spades.push_back(sg);
   }
-  for (auto& c : h->convs) { c.wu_off = 0; c.zero_off = 0; c.wino_m = 0; }
+  for (auto& c : h->convs) { c.wu_off = 0; c.wu4_off = 0; c.zero_off = 0; }
   if (h->prec() == PREC_F32 && !getenv("RIB_NO_WINO")) {
     // 3x3 stride-1 convolutions with >= 128 input channels that own their launch (no fused 1x1 shortcut, no upsampled
     // input): the deep residual blocks of the generator and of the mask network
@@ -553,9 +552,9 @@ void assign_weight_layout(rib_handle* h) {
       // (measured per layer at 512x512, transforms included: 512->512 at 32x32 58 -> 38 us, 256->256 at 64x64 47-52 -> 42 us,
       // 512->256 at 64x64 95 -> 63 us; 128->128 at 64x64 gains nothing: the two transforms cost ~13 us per layer)
       if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 128 % (c.coutp / 4)) continue;
-      // RIB_WINO_M=2: F(2x2, 3x3) (16 positions, 4/9 of the multiplications); default F(4x4, 3x3) (36 positions, 1/4)
-      c.wino_m = (getenv("RIB_WINO_M") && atoi(getenv("RIB_WINO_M")) == 2) ? 2 : 4;
-      c.wu_off = take((size_t)(c.wino_m + 2) * (c.wino_m + 2) * c.coutp * c.cinp);
+      // both transformed filter sets are kept: the plan picks F(4x4) or F(2x2) per layer from the map size (conv_wino)
+      c.wu_off = take((size_t)16 * c.coutp * c.cinp);
+      c.wu4_off = take((size_t)36 * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
     }
   }
@@ -842,7 +841,14 @@ struct Builder {
 
   bool conv_wino(const ConvArgs& a, const std::string& opname, int Hout, int Wout) {
     const ConvDef& c = *a.cd;
-    const int wm = c.wino_m, NP = (wm + 2) * (wm + 2);      // output tile edge, Winograd positions
+    // F(4x4, 3x3) (36 positions, 1/4 of the multiplications) where its per-position GEMM still has >= 256 rows (maps of
+    // 64x64 and more at batch 1); below that the 36 GEMMs are filter-streaming-bound (512x512 filters x 36 = 38 MB for 64
+    // rows) and F(2x2, 3x3) (16 positions, 4/9) is faster.  Measured per layer at 512x512, transforms included:
+    // 256->256 at 64x64 42.4 -> 37.3 us, 512->256 at 64x64 67.4 -> 56.2; 512->512 at 32x32 38.3 -> 41.0 (kept on F(2x2)).
+    // RIB_WINO_M = 2 / 4 forces one of them.
+    const int wino_force = getenv("RIB_WINO_M") ? atoi(getenv("RIB_WINO_M")) : 0;
+    const int wm = wino_force == 2 || wino_force == 4 ? wino_force : ((long)B * ((Hout + 3) / 4) * ((Wout + 3) / 4) >= 256 ? 4 : 2);
+    const int NP = (wm + 2) * (wm + 2);      // output tile edge, Winograd positions
     const int tilesY = (Hout + wm - 1) / wm, tilesX = (Wout + wm - 1) / wm, ntiles = tilesY * tilesX;
     const std::string gname = opname + (wm == 2 ? ".wino" : ".wino4");
     const size_t v_off = alloc((size_t)B * NP * ntiles * c.cinp * sizeof(float));
@@ -881,7 +887,7 @@ struct Builder {
       p.tilesX = (tilesX + v->TW() - 1) / v->TW(); p.tilesY = (tilesY + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       p.act = ACT_NONE; p.ksplit = 1; p.yC = c.coutp; p.yoff = 0; p.Cout = c.coutp;
       p.w_mod = NP; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
-      op.x = WS(v_off); op.w = WT(c.wu_off); op.bias = WT(c.zero_off); op.y = WS(m_off);
+      op.x = WS(v_off); op.w = WT(wm == 2 ? c.wu_off : c.wu4_off); op.bias = WT(c.zero_off); op.y = WS(m_off);
       op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * NP);
       op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 or 1/4 of it)
       P->flops[RIB_KC_IGEMM] += op.flops;
@@ -1747,8 +1753,10 @@ int rib_finalize_weights(rib_handle* h) {
                                     {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
                                     {32.0 / 243, 16.0 / 81, 8.0 / 27},     {32.0 / 243, -16.0 / 81, 8.0 / 27},
                                     {0, 0, 1}};
-    const int T = c.wino_m + 2;
-    const double (*G)[3] = c.wino_m == 2 ? G2 : G4;
+    for (int wm = 2; wm <= 4; wm += 2) {
+    const int T = wm + 2;
+    const double (*G)[3] = wm == 2 ? G2 : G4;
+    const size_t u_off = wm == 2 ? c.wu_off : c.wu4_off;
     for (int o = 0; o < c.cout; ++o)
       for (int i = 0; i < c.cin; ++i) {
         double g[3][3], t[6][3];
@@ -1757,8 +1765,9 @@ int rib_finalize_weights(rib_handle* h) {
           for (int dx = 0; dx < 3; ++dx) t[r][dx] = G[r][0] * g[0][dx] + G[r][1] * g[1][dx] + G[r][2] * g[2][dx];
         for (int r = 0; r < T; ++r)
           for (int q = 0; q < T; ++q)
-            blob[c.wu_off + ((size_t)(r * T + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
+            blob[u_off + ((size_t)(r * T + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
       }
+    }
   }
   if (h->mc16()) {
     // rows of `rowlen` K-contiguous elements: bf16 -> [row][rowlen]; f32x3 -> [row][plane][rowlen] with

@@ -195,7 +195,7 @@ def test_plan_flops_and_shape_rules(lib):
         assert all(int(g) > 0 for g in grid.split(","))
         names.append(name)
     # (the deep 3x3 layers run in the Winograd domain at this size: transform, batched GEMM, transform)
-    for must in ("down_0.0.spade", "res_1.conv_block_1.wino_in", "res_1.conv_block_1.wino4", "res_1.conv_block_1.wino_out", "up_0.conv_block_1", "conv_img",
+    for must in ("down_0.0.spade", "res_1.conv_block_1.wino_in", "res_1.conv_block_1.wino", "res_1.conv_block_1.wino_out", "flow_network_temp.res_flow.2.conv_block_0.wino4", "up_0.conv_block_1", "conv_img",
                  "flow_network_temp.res_flow.3.join", "flow_network_temp.conv_mask.0"):
         assert must in names
     lib.rib_destroy(h)
