@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 from . import rasterise
+from .resize import resize_cubic_u8
 
 
 def sample_rate_of(num_pose: int, num_key: int) -> int:
@@ -56,13 +57,17 @@ def _list(d, exts):
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=3, label_fn=None, png_compress_level=None):
+    def __init__(self, cfg, lanes=3, label_fn=None, png_compress_level=None, resize="cv2"):
         """lanes: independent segments kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (measured on MI355X at 512x512: 284 -> 363 frames/s with 3 lanes;
         the frames inside a segment stay strictly sequential).
         label_fn(frames, H, W) -> [T, 22, H, W]: rasteriser override for models that only speak the
         reference's call protocol (the tests pass the CPU oracle); by default the model's GPU
-        rasteriser is used and a model without one is an error (no host fallback)."""
+        rasteriser is used and a model without one is an error (no host fallback).
+        resize: "cv2" = OpenCV INTER_CUBIC restated (resize.py; what the reference's A.Resize computes), "pil" = PIL BICUBIC."""
+        if resize not in ("cv2", "pil"):
+            raise ValueError("resize must be 'cv2' or 'pil'")
+        self.resize = resize
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
         self.label_fn = label_fn
@@ -101,26 +106,31 @@ class Evaluator:
         return cache[1][:max(1, min(self.lanes, nsegs))]
 
     # ---- per-frame host pre-processing (evaluator.py:205-235) --------------------------------
-    def load_image(self, path):
-        """PIL open -> resize to the model size (cubic) -> [-1,1] CHW (ToTensor + Normalize(.5,.5)).
-        The reference resizes with albumentations/cv2 INTER_CUBIC; PIL's bicubic is used here."""
+    def _decode_resized_u8(self, path):
+        """PIL decode -> RGB uint8 HWC at the model size.  `resize="cv2"` (default): OpenCV's 8-bit INTER_CUBIC restated
+        in resize.py (what the reference's albumentations `A.Resize(interpolation=cv2.INTER_CUBIC)` computes: A = -0.75,
+        no low-pass on reduction; unpinned, cv2 is not in this image); `resize="pil"`: PIL's BICUBIC (round 1)."""
         from PIL import Image
         img = Image.open(path).convert("RGB")
         w0, h0 = img.size
-        if (w0, h0) != (self.width, self.height):
-            img = img.resize((self.width, self.height), Image.BICUBIC)
-        a = np.asarray(img, dtype=np.float32) / 255.0
-        return torch.from_numpy((a - 0.5) / 0.5).permute(2, 0, 1).contiguous(), (w0, h0)
+        if (w0, h0) == (self.width, self.height):
+            return np.asarray(img, dtype=np.uint8), (w0, h0)
+        if self.resize == "pil":
+            return np.asarray(img.resize((self.width, self.height), Image.BICUBIC), dtype=np.uint8), (w0, h0)
+        return resize_cubic_u8(np.asarray(img, dtype=np.uint8), self.width, self.height), (w0, h0)
+
+    def load_image(self, path):
+        """PIL open -> resize to the model size (cubic) -> [-1,1] CHW (ToTensor + Normalize(.5,.5));
+        PGNR/models/evaluator.py:205-221 with `get_alb_transform` (:18-26)."""
+        u8, size0 = self._decode_resized_u8(path)
+        a = u8.astype(np.float32) / 255.0
+        return torch.from_numpy((a - 0.5) / 0.5).permute(2, 0, 1).contiguous(), size0
 
     def load_image_u8(self, path):
         """The same decode + resize, left as uint8 HWC: the pipeline uploads a quarter of the bytes and
         applies ToTensor + Normalize(.5,.5) on the GPU (the same two fp32 operations, bit-identical)."""
-        from PIL import Image
-        img = Image.open(path).convert("RGB")
-        w0, h0 = img.size
-        if (w0, h0) != (self.width, self.height):
-            img = img.resize((self.width, self.height), Image.BICUBIC)
-        return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()), (w0, h0)
+        u8, size0 = self._decode_resized_u8(path)
+        return torch.from_numpy(u8.copy()), size0
 
     def load_pose(self, json_path, orig_size):
         """json -> (landmarks, conf) in model-size pixels: the keypoints follow the image resize

@@ -198,3 +198,37 @@ def test_inference_cli_surface():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     with pytest.raises((ValueError, RuntimeError)):     # missing checkpoint -> ValueError (no GPU here -> RuntimeError first)
         mod.load_generator(cfg)
+
+
+def test_cubic_resize_follows_the_opencv_definition():
+    """The folder driver's resize (render-in-between_amd/resize.py, vectorised) against the scalar restatement of
+    OpenCV's 8-bit INTER_CUBIC in oracle/resize_ref.py (written independently): bit-exact on enlargements, reductions,
+    non-integer ratios, grey and RGB; plus properties of the definition: equal sizes copy, constants stay constant,
+    overshoot saturates, no low-pass on reduction (period-3 stripes reduced 3x stay solid; PIL's BICUBIC averages them)."""
+    from oracle import resize_ref
+    from render_in_between_amd import resize as rz
+    rng = np.random.default_rng(5)
+    for (h0, w0, c, h, w) in ((9, 7, 3, 16, 16), (23, 31, 3, 16, 16), (12, 20, 1, 19, 33), (40, 40, 3, 16, 32), (5, 5, 3, 5, 9), (64, 48, 3, 32, 16)):
+        a = rng.integers(0, 256, size=(h0, w0, c), dtype=np.uint8)
+        if c == 1:
+            a = a[:, :, 0]
+        got = rz.resize_cubic_u8(a, w, h)
+        want = resize_ref.resize_cubic_u8(a, w, h)
+        assert got.shape == want.shape and got.dtype == np.uint8
+        assert np.array_equal(got, want), (h0, w0, c, h, w, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    a = rng.integers(0, 256, size=(16, 16, 3), dtype=np.uint8)
+    assert np.array_equal(rz.resize_cubic_u8(a, 16, 16), a)
+    for v in (0, 1, 127, 254, 255):
+        assert np.all(rz.resize_cubic_u8(np.full((11, 13, 3), v, np.uint8), 32, 16) == v)
+    # overshoot is clipped, not wrapped: a hard edge enlarged 4x stays within [0, 255] and reaches both ends
+    edge = np.zeros((8, 8), np.uint8); edge[:, 4:] = 255
+    up = rz.resize_cubic_u8(edge, 32, 32)
+    assert up.min() == 0 and up.max() == 255 and np.all(up[:, :12] == 0) and np.all(up[:, 20:] == 255)
+    # reduction takes 4 taps at the source pitch (no area filter): reducing 3x lands on source pixel 3*dx + 1 exactly, so
+    # stripes of period 3 come out solid; PIL's BICUBIC widens its kernel on reduction and returns their mean
+    st = np.zeros((48, 48), np.uint8); st[:, 1::3] = 255
+    down = rz.resize_cubic_u8(st, 16, 16)
+    assert np.all(down == 255)
+    from PIL import Image
+    pil = np.asarray(Image.fromarray(st).resize((16, 16), Image.BICUBIC))
+    assert 60 < pil.mean() < 110
