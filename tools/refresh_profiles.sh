@@ -19,6 +19,16 @@ echo "[refresh] PMC passes (separate runs, kernel trace only)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_w.log 2>&1
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${TAG}_pmc_traffic.json
+echo "[refresh] PMC wave counters (matrix-pipe busy, waits, LDS conflicts): three more passes, one counter set each"
+echo "# rocprofv3 --pmc passes over tools/prof_ops.py --run (512x512 B=1), joined with the launch plan by tools/pmc_ops.py" > $OUT/${TAG}_pmc_waves.txt
+echo "# SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (us * 2400 cycles) = fraction of the time a SIMD's matrix pipe is busy" >> $OUT/${TAG}_pmc_waves.txt
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC"; do
+  name=pmc_$(echo $set | cut -c4-12)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$name -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_$name.log 2>&1
+  echo "" >> $OUT/${TAG}_pmc_waves.txt; echo "## $name" >> $OUT/${TAG}_pmc_waves.txt
+  python3 $ROOT/tools/pmc_ops.py $OUT/$name >> $OUT/${TAG}_pmc_waves.txt
+  rm -rf $OUT/$name
+done
 echo "[refresh] other shapes and modes"
 rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
 for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype f32x3" "--dtype f32x3 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
