@@ -110,6 +110,7 @@ struct ConvDef {
   // Winograd F(2x2, 3x3) filters U = G g G^T, [16 positions][CoutPad][CinPad] fp32, and a zero bias vector for the
   // batched GEMM (the real bias is added by the output transform); 0: the layer never runs that way
   size_t wu_off = 0, wu4_off = 0, zero_off = 0;   // Winograd-domain filters: F(2x2,3x3) [16][coutp][cinp], F(4x4,3x3) [36][coutp][cinp]
+  size_t wl_off = 0; int lowc_ce = 0, lowc_ncol = 0;   // k_conv_lowc filter [9*CE/KG][KG][NCOL] (real-channel K order), CE / NCOL of its instantiation
 };
 
 struct TensorDef {
@@ -353,7 +354,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
-enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE, OP_WINO_IN, OP_WINO_OUT };
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE, OP_WINO_IN, OP_WINO_OUT, OP_LOWC };
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
@@ -402,6 +403,7 @@ struct Op {
   InAddParams ap; PRef a_t1, a_sc1, a_sh1, a_ts, a_scs, a_shs, a_x, a_out;
   // pack
   PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
+  LowcParams lc; PRef lc_s0, lc_s1, lc_s2, lc_w, lc_bias, lc_y, lc_stat; int lowc_ce = 0, lowc_ncol = 0;
   // Winograd transforms
   WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v;
   WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
@@ -421,6 +423,9 @@ struct Tap { std::string name; size_t off; int Cp, C, H, W; };
 struct Act {       // NHWC activation in the workspace
   size_t off = 0;  // bytes
   int Cp = 0, C = 0, H = 0, W = 0;
+  // virt: never materialised - the channel concatenation of up to three of the caller's NCHW fp32 tensors, read in place
+  // by k_conv_lowc (usrc: user slots, uc: their channel counts)
+  bool virt = false; int usrc[3] = {0, 0, 0}, uc[3] = {0, 0, 0};
 };
 struct PendingStats;
 struct Norm {      // (scale, shift) arrays [B][ld]
@@ -511,6 +516,21 @@ const ConvDef& conv_of(const rib_handle* h, const std::string& name) {
 // ------------------------------------------------------------------------------------------
 // weight layout: sizes are fixed by the config, so offsets are assigned at create time
 // ------------------------------------------------------------------------------------------
+// k_conv_lowc instantiations: (channels rounded up to the MFMA's k-group, output columns)
+static bool lowc_instantiated(int ce, int ncol) {
+  return (ce == 6 && ncol == 64) || (ce == 10 && ncol == 32) || (ce == 22 && ncol == 32) || (ce == 24 && ncol == 16);
+}
+template <int CE, int NCOL> static void launch_lowc_t(bool bf16, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false>), grid, dim3(256), 0, st, p);
+}
+static void launch_lowc(int ce, int ncol, bool bf16, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(bf16, grid, st, p);
+  else if (ce == 10 && ncol == 32) launch_lowc_t<10, 32>(bf16, grid, st, p);
+  else if (ce == 22 && ncol == 32) launch_lowc_t<22, 32>(bf16, grid, st, p);
+  else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(bf16, grid, st, p);
+}
+
 void assign_weight_layout(rib_handle* h) {
   size_t off = 0;
   h->spades.clear(); h->spade_index.clear();
@@ -557,6 +577,16 @@ void assign_weight_layout(rib_handle* h) {
       c.wu4_off = take((size_t)36 * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
     }
+  }
+  // first-layer convolutions over the caller's tensors (k_conv_lowc, every precision mode): filter in real-channel K order
+  for (auto& c : h->convs) {
+    c.wl_off = 0; c.lowc_ce = c.lowc_ncol = 0;
+    if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || getenv("RIB_NO_LOWC")) continue;
+    const int ncol = c.coutp;
+    const int ce = ncol == 16 ? (c.cin + 3) / 4 * 4 : (c.cin + 1) / 2 * 2;
+    if (!lowc_instantiated(ce, ncol)) continue;
+    c.lowc_ce = ce; c.lowc_ncol = ncol;
+    c.wl_off = take((size_t)9 * ce * ncol);
   }
   if (h->mc16()) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float); f32x3: three planes
     const size_t pl = h->compute_x3 ? 3 : 1;
@@ -652,7 +682,7 @@ struct Builder {
     P->ops.push_back(op);
   }
   // record an event after the last op pushed
-  int record_after_last() { const int e = new_event(); P->ops.back().record_ev = e; return e; }
+  int record_after_last() { if (P->ops.empty()) return -1; const int e = new_event(); P->ops.back().record_ev = e; return e; }   // -1: nothing to wait for
   void wait_before_next(int ev) { if (ev >= 0) pending_waits.push_back(ev); }
 
   // Workspace layout.  During the build every buffer gets its own range of a virtual address space (bump
@@ -677,6 +707,26 @@ struct Builder {
     n.sh = alloc((size_t)B * Cp * sizeof(float));
     return n;
   }
+  // an activation that is never materialised: up to three of the caller's NCHW tensors, concatenated along channels
+  Act virt(int C, int H, int W, int s0, int c0, int s1 = 0, int c1 = 0, int s2 = 0, int c2 = 0) {
+    Act a; a.virt = true; a.C = C; a.Cp = 0; a.H = H; a.W = W;
+    a.usrc[0] = s0; a.uc[0] = c0; a.usrc[1] = s1; a.uc[1] = c1; a.usrc[2] = s2; a.uc[2] = c2;
+    return a;
+  }
+  // every consumer of a packed input tensor has a k_conv_lowc instantiation (and the plan is single-stream: the side-stream
+  // experiment forks at the pack launches)
+  bool lowc_serves(std::initializer_list<const char*> names) {
+    if (h->use_streams || getenv("RIB_LBL_AT")) return false;
+    for (const char* nm : names) {
+      auto it = h->conv_index.find(nm);
+      if (it == h->conv_index.end() || !h->convs[it->second].wl_off) return false;
+    }
+    return true;
+  }
+  // conv_img can skip its NHWC copy only on the head kernel (conv(): `small` + `head`)
+  bool head_without_nhwc(const ConvDef& c) {
+    return c.cout <= 3 && c.ks == 3 && c.stride == 1 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_SMALLCONV") && !getenv("RIB_NO_HEADCONV");
+  }
   static PRef WS(size_t off) { PRef r; r.sp = PS_WS; r.off = off; return r; }
   static PRef WT(size_t off) { PRef r; r.sp = PS_WEIGHT; r.off = off; return r; }
   static PRef US(int slot) { PRef r; r.sp = PS_USER; r.off = (size_t)slot; return r; }
@@ -696,6 +746,7 @@ struct Builder {
     const ConvDef* aux = nullptr; Act aux_in;   // fused 1x1 shortcut operand (accumulated into the same output)
     PRef y_nchw;            // optional NCHW copy
     PRef y_user;            // when set, y is this user tensor (yC = cout exactly)
+    bool y_none = false;    // no NHWC destination at all (a head that only writes its NCHW copy)
     bool want_stats = false;
     Norm* stats_out = nullptr; size_t stats_choff = 0;  // finalize target (+channel offset)
     bool affine = false;    // finalize with the conv's IN gamma/beta
@@ -706,6 +757,7 @@ struct Builder {
     const ConvDef& c = *a.cd;
     const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
     const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
+    if (a.in.virt) return conv_lowc(a, opname);
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
     {
       // Winograd F(2x2, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h)
@@ -774,6 +826,8 @@ struct Builder {
     }
     if (a.y_user.sp != PS_NULL) {
       op.y = a.y_user; p.yC = c.cout; p.yoff = 0; p.Cout = c.cout; p.y_f32 = 1;   // a caller's fp32 tensor
+    } else if (a.y_none) {
+      op.y = PRef(); p.yC = 0; p.yoff = 0; p.Cout = a.cout_store >= 0 ? a.cout_store : c.cout;
     } else {
       op.y = WS(a.out.off); p.yC = a.out.Cp; p.yoff = a.yoff;
       p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
@@ -781,6 +835,9 @@ struct Builder {
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
+    if (a.y_none && !(small && c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV") && a.y_nchw.sp != PS_NULL)) {
+      error = opname + ": only the head kernel can run without an NHWC destination"; return false;
+    }
     if (small) {
       op.small_co = c.cout;
       op.head = c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV");
@@ -834,6 +891,45 @@ struct Builder {
       f.grid = dim3(c.coutp / 16, B, 1);
       // (a channel offset means two producers share the arrays - the concatenated encoders of the mask network -
       // and consumers would need two partial sources: those keep their launch)
+      finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
+    }
+    return true;
+  }
+
+  // first-layer 3x3 convolution over the caller's NCHW tensors (k_conv_lowc): no packed copy, reduction over the real channels
+  bool conv_lowc(const ConvArgs& a, const std::string& opname) {
+    const ConvDef& c = *a.cd;
+    const int H = a.in.H, W = a.in.W;
+    if (!c.wl_off || c.ks != 3 || c.stride != 1 || a.ups || a.pro || a.res || a.aux || a.y_nchw.sp != PS_NULL || a.y_user.sp != PS_NULL ||
+        a.in.uc[0] + a.in.uc[1] + a.in.uc[2] != c.cin) { error = opname + ": not a layer k_conv_lowc can run"; return false; }
+    if (a.out.H != H || a.out.W != W) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
+    Op op; op.kind = OP_LOWC; op.kclass = RIB_KC_IGEMM; op.name = opname; op.lowc_ce = c.lowc_ce; op.lowc_ncol = c.lowc_ncol;
+    memset(&op.lc, 0, sizeof op.lc);
+    LowcParams& p = op.lc;
+    p.c0 = a.in.uc[0]; p.c1 = a.in.uc[1]; p.c2 = a.in.uc[2];
+    p.H = H; p.W = W; p.yC = a.out.Cp; p.yoff = a.yoff; p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
+    p.act = a.act; p.CoutPad = c.coutp;
+    p.tilesX = (W + 31) / 32; p.tilesY = (H + 7) / 8;
+    if (p.Cout > c.lowc_ncol || c.coutp > c.lowc_ncol) { error = opname + ": more output columns than the k_conv_lowc instantiation has"; return false; }
+    op.lc_s0 = US(a.in.usrc[0]); if (p.c1) op.lc_s1 = US(a.in.usrc[1]); if (p.c2) op.lc_s2 = US(a.in.usrc[2]);
+    op.lc_w = WT(c.wl_off); op.lc_bias = WT(c.b_off); op.lc_y = WS(a.out.off);
+    const int tiles = p.tilesX * p.tilesY;
+    size_t part_off = 0;
+    if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(double)); op.lc_stat = WS(part_off); }
+    op.grid = dim3(tiles, B, 1);
+    op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)H * W * B;
+    P->flops[RIB_KC_IGEMM] += op.flops;
+    push(op);
+    if (a.want_stats) {
+      Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
+      memset(&f.fp, 0, sizeof f.fp);
+      f.fp.tiles = tiles; f.fp.Cs = c.coutp; f.fp.C = h->padc(c.cout);
+      f.fp.ld = a.stats_out->ld; f.fp.off = (int)a.stats_choff;
+      f.fp.inv_count = 1.0f / ((float)H * (float)W); f.fp.eps = 1e-5f;
+      f.f_part = WS(part_off);
+      if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
+      f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
+      f.grid = dim3(c.coutp / 16, B, 1);
       finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
     }
     return true;
@@ -1079,7 +1175,8 @@ struct Builder {
                    &op.s_slab, &op.s_bias, &op.s_y, &op.s_res, &op.s_stat, &op.m_slab, &op.m_bias, &op.m_xm, &op.m_sc, &op.m_sh,
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
                    &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst,
-                   &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat};
+                   &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat,
+                   &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat};
     for (PRef* r : all) if (r->sp == PS_WS) f(*r);
   }
   AllocRec* alloc_of(size_t voff) {
@@ -1155,9 +1252,10 @@ struct Builder {
     const int H = P->H, W = P->W;
     P->labels_only = true;
     defer_stats = false;
-    Act L = act(c.label_nc, H, W);
-    if (L.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }
-    {
+    const bool vL = lowc_serves({"down_first", "flow_network_temp.down_lbl.0"});
+    Act L = vL ? virt(c.label_nc, H, W, U_LABEL, c.label_nc) : act(c.label_nc, H, W);
+    if (!vL && L.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }
+    if (!vL) {
       Op op; op.kind = OP_PACK; op.kclass = RIB_KC_PACK; op.name = "pack.label";
       memset(&op.kp, 0, sizeof op.kp);
       op.kp.c0 = c.label_nc; op.kp.c1 = 0; op.kp.c2 = 0; op.kp.dC = L.Cp; op.kp.HW = H * W;
@@ -1185,9 +1283,13 @@ struct Builder {
     const int D = c.num_down_img;
 
     // ---- boundary: NCHW user tensors -> NHWC (+concat, +zero channel padding) ----
-    Act L = act(c.label_nc, H, W);
-    Act Ein = act(c.image_nc * 2, H, W);
-    Act I9 = act(c.image_nc * 3, H, W);
+    // Where the first layers can read the caller's NCHW tensors in place (k_conv_lowc) there is no packed copy at all
+    const bool vL = lowc_serves({"down_first", "flow_network_temp.down_lbl.0"});
+    const bool vE = lowc_serves({"ref_embedding.conv_first"});
+    const bool vI = lowc_serves({"flow_network_temp.down_img.0"}) && head_without_nhwc(conv_of(h, "conv_img"));
+    Act L = vL ? virt(c.label_nc, H, W, U_LABEL, c.label_nc) : act(c.label_nc, H, W);
+    Act Ein = vE ? virt(c.image_nc * 2, H, W, U_FAKE, c.image_nc, U_PREV, c.image_nc) : act(c.image_nc * 2, H, W);     // cat([img_fake, img_prev]) generator.py:197
+    Act I9 = vI ? virt(c.image_nc * 3, H, W, U_PREV, c.image_nc, U_FAKE, c.image_nc, U_IMG, c.image_nc) : act(c.image_nc * 3, H, W);   // cat([img_prev, img_fake, img]) generator.py:232
     auto pack = [&](const std::string& nm, const Act& dst, int s0, int c0, int s1, int c1) {
       Op op; op.kind = OP_PACK; op.kclass = RIB_KC_PACK; op.name = nm;
       memset(&op.kp, 0, sizeof op.kp);
@@ -1197,17 +1299,17 @@ struct Builder {
       op.grid = dim3((H * W + 63) / 64, B, 1);
       push(op);
     };
-    if (L.Cp > 32 || Ein.Cp > 32 || I9.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }
+    if (L.Cp > 32 || Ein.Cp > 32 || I9.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }   // (Cp = 0 for the unpacked ones)
     mark_label = true;
-    pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
+    if (!vL) pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
     mark_label = false;
     const int ev_label = record_after_last();   // also the fork point of the side streams
-    pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
+    if (!vI) pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
     // RIB_LBL_AT=<i>: (experiment) only the label branch goes to a side stream, forked when the main
     // chain reaches down_<i>, i.e. next to the small-map layers that cannot fill the chip
     const int lbl_at = getenv("RIB_LBL_AT") ? atoi(getenv("RIB_LBL_AT")) : -1;
     if (lbl_at < 0) { cur_stream = ST_EMBED; wait_before_next(ev_label); }
-    pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
+    if (!vE) pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
 
     // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
     std::vector<Act> cond(c.emb_down + 1);
@@ -1313,6 +1415,7 @@ struct Builder {
       const ConvDef& ci = conv_of(h, "conv_img");
       ConvArgs a; a.cd = &ci; a.in = x; a.pro_lrelu = true; a.out = I9; a.yoff = c.image_nc * 2;
       a.cout_store = c.image_nc; a.act = ACT_TANH; a.y_nchw = US(U_IMG);
+      a.y_none = I9.virt;      // the mask network then reads the image from the caller's NCHW tensor
       if (!conv(a, "conv_img")) return false;
     }
 
@@ -1532,6 +1635,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_out, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_wino_out, op.grid, dim3(256), 0, st, p);
       } break;
+      case OP_LOWC: {
+        LowcParams p = op.lc;
+        p.s0 = R.get<const float>(op.lc_s0); p.s1 = R.get<const float>(op.lc_s1); p.s2 = R.get<const float>(op.lc_s2);
+        p.w = R.get<const float>(op.lc_w); p.bias = R.get<const float>(op.lc_bias); p.y = R.get<float>(op.lc_y);
+        p.stat_part = R.get<double>(op.lc_stat);
+        launch_lowc(op.lowc_ce, op.lowc_ncol, bf16, op.grid, st, p);
+      } break;
       case OP_PACK: {
         PackParams p = op.kp;
         p.s0 = R.get<const float>(op.k_s0); p.s1 = R.get<const float>(op.k_s1); p.s2 = R.get<const float>(op.k_s2);
@@ -1742,6 +1852,18 @@ int rib_finalize_weights(rib_handle* h) {
         blob[sg.b_off + colb] = b[sg.C + ch];
       }
     }
+  }
+  for (auto& c : h->convs) {
+    if (!c.used || !c.wl_off) continue;
+    // k_conv_lowc: [step][k within the MFMA's group][column], k = tap * CE + channel over the REAL channels (zero for the
+    // channels that round Cin up to the group and for columns beyond Cout)
+    const int CE = c.lowc_ce, N = c.lowc_ncol, KG = N == 16 ? 4 : 2;
+    for (int k = 0; k < 9 * CE; ++k) {
+      const int tap = k / CE, ch = k % CE;
+      for (int col = 0; col < N; ++col)
+        blob[c.wl_off + (size_t)k * N + col] = (col < c.cout && ch < c.cin) ? blob[c.w_off + ((size_t)col * 9 + tap) * c.cinp + ch] : 0.f;
+    }
+    (void)KG;   // (step s, slot j) = (k / KG, k % KG): the rows are already in k order
   }
   for (auto& c : h->convs) {
     if (!c.used || !c.wu_off) continue;
@@ -2181,6 +2303,9 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
              op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
+  else if (op.kind == OP_LOWC)
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|lowc (caller's NCHW tensors, K = 9 x %d real channels) 8x32 tile, %d columns|%.0f", op.name.c_str(), op.kclass,
+             op.grid.x, op.grid.y, op.grid.z, op.lowc_ce, op.lowc_ncol, op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;

@@ -756,3 +756,58 @@ def test_winograd_path_agrees_with_the_direct_convolutions(monkeypatch, wino_m):
         del G1, G2
     monkeypatch.delenv("RIB_NO_WINO", raising=False)
     monkeypatch.delenv("RIB_WINO_M", raising=False)
+
+
+def test_first_layers_read_the_callers_tensors_in_place(monkeypatch):
+    """The four first-layer 3x3 convolutions (ref_embedding.conv_first 6 -> 64, flow_network_temp.down_img.0 9 -> 32 /
+    down_lbl.0 22 -> 32, down_first 22 -> 16) run as k_conv_lowc: the halo tile gathered from the caller's NCHW tensors,
+    K over the real channels, no pack launches, conv_img without its NHWC copy.  Against the same frame with
+    RIB_NO_LOWC=1 (pack + k_igemm over zero-padded channels) and against the oracle, per tap at 64x64; sizes whose
+    width is not a multiple of the 32-pixel tile, a batch, and a 5-step chain (the labels-only batch plan uses the
+    same kernel)."""
+    spec, sd, _ = build("full", 0)
+    R = oracle(spec, sd)
+    for (B, H, W, seed) in ((1, 64, 64, 11), (2, 48, 80, 12), (1, 176, 112, 13), (1, 256, 256, 14)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        monkeypatch.delenv("RIB_NO_LOWC", raising=False)
+        G1 = rib.Generator(rib.hsm_gen_config()).eval(); G1.load_state_dict(sd)
+        info = G1.launch_info(B, H, W)
+        names = [o["name"] for o in info]
+        assert not any(n.startswith("pack.") for n in names), names[:6]
+        lowc = [o["name"] for o in info if o["tile"].startswith("lowc")]
+        assert sorted(lowc) == sorted(["ref_embedding.conv_first", "flow_network_temp.down_img.0", "flow_network_temp.down_lbl.0", "down_first"])
+        if (H, W) == (64, 64):
+            G1.enable_taps()
+        i1, m1 = [t.clone() for t in G1(label, None, fake, prev)]
+        if (H, W) == (64, 64):
+            taps = G1.read_taps(B, H, W)
+            otaps = {}
+            R(label, None, fake, prev, taps=otaps)
+            for k in ("cond_0", "down_first", "mask.lbl_0.raw", "mask.img_0.raw", "mask.cat.raw"):
+                assert float((taps[k] - otaps[k]).abs().max()) / max(1.0, float(otaps[k].abs().max())) <= 2e-5, k
+        monkeypatch.setenv("RIB_NO_LOWC", "1")
+        G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
+        n2 = [o["name"] for o in G2.launch_info(B, H, W)]
+        assert "pack.label" in n2 and "pack.img9" in n2 and "pack.embed_in" in n2
+        i2, m2 = G2(label, None, fake, prev)
+        torch.cuda.synchronize()
+        e = max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max()))
+        assert e < 5e-5, (B, H, W, e)
+        oi, om = R(label, None, fake, prev)
+        assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL, (B, H, W)
+        del G2
+        if (H, W) == (48, 80):
+            # chain: frame t of the segment == the per-frame call on (label_t, dain_t, fused_{t-1})
+            monkeypatch.delenv("RIB_NO_LOWC", raising=False)
+            T = 5
+            labels = torch.stack([synth.make_inputs(spec, B, H, W, 100 + t)[0] for t in range(T)])
+            dains = torch.stack([synth.make_inputs(spec, B, H, W, 100 + t)[1] for t in range(T)])
+            key = prev.cuda()
+            _, _, fused = G1.chain(key, labels.cuda(), dains.cuda())
+            p = key
+            for t in range(T):
+                _, _, f = G1.forward_blend(labels[t].cuda(), None, dains[t].cuda(), p)
+                assert torch.equal(f, fused[t]), t
+                p = f.clone()
+        del G1
+    monkeypatch.delenv("RIB_NO_LOWC", raising=False)
