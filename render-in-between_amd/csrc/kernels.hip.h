@@ -2079,10 +2079,13 @@ __global__ __launch_bounds__(256) void k_gather6(const Gather6Params p) {
 // 16-column path), and the input is read where the caller left it:
 //   * the halo tile (10 x 34 pixels x CE channels) is gathered straight from up to three NCHW fp32 tensors (coalesced
 //     along x; torch.cat at PGNR/models/generator.py:197,232 happens in this gather) into LDS at an odd channel pitch;
-//   * the whole filter [K/2][2][NCOL] (K-pair-major, so a fragment read is 32 consecutive words) is staged once;
+//   * the filter fragments [K/2][2][NCOL] (K-pair-major: a fragment is 32 consecutive words) live in REGISTERS, K/2 x NF
+//     of them per lane, loaded once from global memory: fp32 32x32x2 MFMAs consume 512 operand bytes per 16 issue
+//     cycles, i.e. the LDS's whole 128 B/clk per CU when both operands come from it (the first version did that and ran
+//     at 45 TFLOP/s, slower than k_igemm); with B in registers LDS delivers one A word per lane and MFMA;
 //   * ONE barrier per workgroup, then K/2 steps of {one 4-byte LDS read per M fragment at a compile-time offset from the
-//     lane's pixel, one per column fragment, MFMA}: consecutive k of a pair are consecutive channels of the same tap,
-//     so lane half lh adds 4 bytes and everything else is an immediate;
+//     lane's pixel, MFMAs}: consecutive k of a pair are consecutive channels of the same tap, so lane half lh adds
+//     4 bytes and everything else is an immediate;
 //   * epilogue as k_igemm's: bias, activation, NHWC store in the storage type, fp64 statistics partials per tile.
 // Workgroup = 8 x 32 output pixels, 4 waves x 2 rows; NCOL = 32 / 64: v_mfma_f32_32x32x2_f32 (fragment = 32 pixels of a
 // row); NCOL = 16: v_mfma_f32_16x16x4_f32 (fragment = 16 pixels).  fp32 arithmetic in every precision mode (the inputs
@@ -2110,7 +2113,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   constexpr int S = 9 * CE / KG;                 // MFMA steps
   constexpr int NF = N16 ? 1 : NCOL / 32;
   __shared__ __attribute__((aligned(16))) float sA[IH * IW * CP];
-  __shared__ __attribute__((aligned(16))) float sW[S * KG * NCOL];
   __shared__ __attribute__((aligned(16))) double red[4][NCOL][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
@@ -2118,21 +2120,42 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   const int ty0 = (tile / p.tilesX) * TH, tx0 = (tile % p.tilesX) * TW;
   const int ctot = p.c0 + p.c1 + p.c2;
   const size_t HW = (size_t)p.H * p.W;
-  // ---- stage the filter and the halo tile ----
-  for (int i = tid * 4; i < S * KG * NCOL; i += 1024) *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(p.w + i);
-  for (int i = tid; i < CE * IH * IW; i += 256) {
-    const int c = i / (IH * IW), rem = i - c * (IH * IW);
-    const int y = rem / IW, x = rem - y * IW;
-    const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
-    float v = 0.f;
-    if (c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-      const float* src; int cc, cn;
-      if (c < p.c0) { src = p.s0; cc = c; cn = p.c0; }
-      else if (c < p.c0 + p.c1) { src = p.s1; cc = c - p.c0; cn = p.c1; }
-      else { src = p.s2; cc = c - p.c0 - p.c1; cn = p.c2; }
-      v = src[((size_t)n * cn + cc) * HW + (size_t)gy * p.W + gx];
+  // ---- stage the halo tile: all of a thread's loads are issued before the first LDS store (one memory round trip) ----
+  {
+    constexpr int TOT = CE * IH * IW, NIT = (TOT + 255) / 256;
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int c = i / (IH * IW), rem = i - c * (IH * IW);
+      const int y = rem / IW, x = rem - y * IW;
+      const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
+      v[it] = 0.f;
+      if (i < TOT && c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        const float* src; int cc, cn;
+        if (c < p.c0) { src = p.s0; cc = c; cn = p.c0; }
+        else if (c < p.c0 + p.c1) { src = p.s1; cc = c - p.c0; cn = p.c1; }
+        else { src = p.s2; cc = c - p.c0 - p.c1; cn = p.c2; }
+        v[it] = src[((size_t)n * cn + cc) * HW + (size_t)gy * p.W + gx];
+      }
     }
-    sA[(y * IW + x) * CP + c] = v;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int c = i / (IH * IW), rem = i - c * (IH * IW);
+      const int y = rem / IW, x = rem - y * IW;
+      if (i < TOT) sA[(y * IW + x) * CP + c] = v[it];
+    }
+  }
+  // ---- this lane's filter fragments (registers; after the staging so that its 30 values in flight are dead: 116 instead
+  // of 198 VGPRs on the 22-channel layers) ----
+  float bw[S][NF];
+  {
+    const float* pw = N16 ? p.w + (lane >> 4) * 16 + (lane & 15) : p.w + (lane >> 5) * NCOL + (lane & 31);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bw[s][nf] = pw[s * KG * NCOL + nf * 32];
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;                      // this lane's column: sum and sum of squares over its valid pixels
@@ -2146,19 +2169,15 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
     const float* pa = sA + ((wave * 2) * IW + li) * CP + lh;       // window origin of pixel (row 2*wave, x = li), k parity lh
-    const float* pb = sW + lh * NCOL + li;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int tap = (2 * s) / CE, c = (2 * s) % CE;
       const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
-      float b[NF];
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) b[nf] = pb[s * 2 * NCOL + nf * 32];
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
         const float a = pa[off + mf * IW * CP];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nf], acc[mf][nf], 0, 0, 0);
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s][nf], acc[mf][nf], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -2194,15 +2213,13 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[f][r] = 0.f;
     const float* pa = sA + ((wave * 2) * IW + l15) * CP + lq;
-    const float* pb = sW + lq * 16 + l15;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int tap = (4 * s) / CE, c = (4 * s) % CE;
       const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
-      const float b = pb[s * 64];
 #pragma unroll
       for (int f = 0; f < 4; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + ((f >> 1) * IW + (f & 1) * 16) * CP], b, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + ((f >> 1) * IW + (f & 1) * 16) * CP], bw[s][0], acc[f], 0, 0, 0);
     }
     const int col = l15;
     const float bv = p.bias[col];
@@ -2229,11 +2246,13 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   }
   if (p.stat_part) {
     __syncthreads();
-    for (int c = tid; c < NCOL; c += 256) {
+    for (int c = tid; c < p.CoutPad; c += 256) {
       double a1 = 0.0, a2 = 0.0;
+      if (c < NCOL) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a1 += red[w][c][0]; a2 += red[w][c][1]; }
-      if (c < p.CoutPad) {
+        for (int w = 0; w < 4; ++w) { a1 += red[w][c][0]; a2 += red[w][c][1]; }
+      }
+      {
         double* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
         dst[c] = a1;
         dst[p.CoutPad + c] = a2;

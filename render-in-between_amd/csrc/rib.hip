@@ -582,7 +582,7 @@ void assign_weight_layout(rib_handle* h) {
   for (auto& c : h->convs) {
     c.wl_off = 0; c.lowc_ce = c.lowc_ncol = 0;
     if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || getenv("RIB_NO_LOWC")) continue;
-    const int ncol = c.coutp;
+    const int ncol = c.cout <= 16 ? 16 : c.coutp;      // (coutp is a multiple of 32; the 16-column instantiation serves Cout <= 16)
     const int ce = ncol == 16 ? (c.cin + 3) / 4 * 4 : (c.cin + 1) / 2 * 2;
     if (!lowc_instantiated(ce, ncol)) continue;
     c.lowc_ce = ce; c.lowc_ncol = ncol;
@@ -910,7 +910,7 @@ struct Builder {
     p.H = H; p.W = W; p.yC = a.out.Cp; p.yoff = a.yoff; p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
     p.act = a.act; p.CoutPad = c.coutp;
     p.tilesX = (W + 31) / 32; p.tilesY = (H + 7) / 8;
-    if (p.Cout > c.lowc_ncol || c.coutp > c.lowc_ncol) { error = opname + ": more output columns than the k_conv_lowc instantiation has"; return false; }
+    if (p.Cout > c.lowc_ncol || c.cout > c.lowc_ncol) { error = opname + ": more output columns than the k_conv_lowc instantiation has"; return false; }
     op.lc_s0 = US(a.in.usrc[0]); if (p.c1) op.lc_s1 = US(a.in.usrc[1]); if (p.c2) op.lc_s2 = US(a.in.usrc[2]);
     op.lc_w = WT(c.wl_off); op.lc_bias = WT(c.b_off); op.lc_y = WS(a.out.off);
     const int tiles = p.tilesX * p.tilesY;

@@ -62,6 +62,8 @@ def main():
         for i in range(lib.rib_num_launches(h, B, H, W)):
             lib.rib_debug_launch_info(h, B, H, W, i, buf, 512)
             name, kclass, grid, tile, flops = buf.value.decode().split("|")
+            if tile.startswith("lowc"):
+                continue            # k_conv_lowc has one implementation per layer shape: nothing to choose
             if int(kclass) in (0, 1) and (args.only is None or args.only in name):
                 ops.append((name, int(kclass), float(flops), tile))
         usec = C.c_double()
