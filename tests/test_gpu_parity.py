@@ -542,7 +542,8 @@ def test_head_convolutions_agree_across_their_three_kernels(monkeypatch):
             del G
         monkeypatch.delenv("RIB_NO_SMALLCONV", raising=False)
 
-        assert launches[0] == launches[1] and abs(launches[1] - launches[2]) <= 1     # (k_igemm may split K at these sizes)
+        # (without the head kernel conv_img writes its NHWC copy again and pack.img9 is back: +1; k_igemm may split K at these sizes)
+        assert 0 <= launches[1] - launches[0] <= 1 and abs(launches[1] - launches[2]) <= 1
         for (i, m) in outs[1:]:
             e = max(float((outs[0][0] - i).abs().max()), float((outs[0][1] - m).abs().max()))
             assert e < (2e-6 if H >= 48 else 1e-5), (B, H, W, e)     # (a 1x1 deepest map amplifies rounding: see the edge-shape test)
