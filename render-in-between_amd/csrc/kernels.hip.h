@@ -2087,9 +2087,9 @@ __global__ __launch_bounds__(256) void k_gather6(const Gather6Params p) {
 //     lane's pixel, MFMAs}: consecutive k of a pair are consecutive channels of the same tap, so lane half lh adds
 //     4 bytes and everything else is an immediate;
 //   * epilogue as k_igemm's: bias, activation, NHWC store in the storage type, fp64 statistics partials per tile.
-// Workgroup = 8 x 32 output pixels, 4 waves x 2 rows; NCOL = 32 / 64: v_mfma_f32_32x32x2_f32 (fragment = 32 pixels of a
-// row); NCOL = 16: v_mfma_f32_16x16x4_f32 (fragment = 16 pixels).  fp32 arithmetic in every precision mode (the inputs
-// are the caller's fp32 tensors).  grid (tilesX * tilesY, B).
+// Workgroup = 8 x 32 (or 8 x 16) output pixels, 4 waves x 2 rows; NCOL = 32 / 64: v_mfma_f32_32x32x2_f32 (fragment = 32
+// pixels of a row, or 2 rows x 16); NCOL = 16: v_mfma_f32_16x16x4_f32 (fragment = 16 pixels).  fp32 arithmetic (the inputs
+// are the caller's fp32 tensors); used by the fp32-storage modes.  grid (tilesX * tilesY, B).
 // ---------------------------------------------------------------------------------------------
 struct LowcParams {
   const float* s0; const float* s1; const float* s2; int c0, c1, c2;   // NCHW sources [B][ci][H][W], concatenated along channels
@@ -2102,12 +2102,14 @@ struct LowcParams {
   int tilesX, tilesY;
 };
 
-template <int CE, int NCOL, bool BF16>
+template <int CE, int NCOL, bool BF16, int TW = 32>
 __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   constexpr bool N16 = NCOL == 16;
   static_assert(NCOL == 16 || NCOL == 32 || NCOL == 64, "16-, 32- or 64-column layers");
   static_assert(CE % (N16 ? 4 : 2) == 0, "channel count rounded up to the k-group of one MFMA");
-  constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;
+  static_assert(TW == 32 || TW == 16, "8x32 or 8x16 pixel tiles");
+  constexpr int TH = 8, IH = TH + 2, IW = TW + 2;
+  constexpr int MF = TW / 16;                   // 32-pixel fragments per wave: one row each (TW = 32) or one fragment of 2 rows x 16
   constexpr int CP = CE + 1;                     // odd LDS pitch: the 32 (16) pixels of a fragment read 32 (16) different banks
   constexpr int KG = N16 ? 4 : 2;                // k per MFMA
   constexpr int S = 9 * CE / KG;                 // MFMA steps
@@ -2161,20 +2163,21 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   double s1 = 0.0, s2 = 0.0;                      // this lane's column: sum and sum of squares over its valid pixels
   if constexpr (!N16) {
     const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[2][NF];
+    f32x16 acc[MF][NF];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-    const float* pa = sA + ((wave * 2) * IW + li) * CP + lh;       // window origin of pixel (row 2*wave, x = li), k parity lh
+    // window origin of this lane's pixel: (row 2*wave [+ mf], x = li) or, 16 wide, (row 2*wave + li/16, x = li%16); k parity lh
+    const float* pa = sA + (TW == 32 ? ((wave * 2) * IW + li) : ((wave * 2 + (li >> 4)) * IW + (li & 15))) * CP + lh;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int tap = (2 * s) / CE, c = (2 * s) % CE;
       const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
+      for (int mf = 0; mf < MF; ++mf) {
         const float a = pa[off + mf * IW * CP];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s][nf], acc[mf][nf], 0, 0, 0);
@@ -2187,11 +2190,12 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       const bool cok = col < p.Cout;
       double c1 = 0.0, c2 = 0.0;
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) {
-        const int oy = ty0 + wave * 2 + mf;
+      for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ox = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;           // pixel of the fragment
+          const int oy = ty0 + wave * 2 + (TW == 32 ? mf : (m >> 4));
+          const int ox = tx0 + (TW == 32 ? m : (m & 15));
           float v = apply_act(acc[mf][nf][r] + bv, p.act);
           if (BF16) v = bf16_round(v);
           const bool ok = cok && oy < p.H && ox < p.W;
@@ -2207,9 +2211,10 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
     }
   } else {
     const int l15 = lane & 15, lq = lane >> 4;
-    f32x4 acc[4];                                  // fragments: (row 2*wave + f/2, x half f%2)
+    constexpr int NFR = TW / 8;                    // 16-pixel fragments per wave: (row 2*wave + f/2, x half f%2) or (row 2*wave + f)
+    f32x4 acc[NFR];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NFR; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[f][r] = 0.f;
     const float* pa = sA + ((wave * 2) * IW + l15) * CP + lq;
@@ -2218,18 +2223,18 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       const int tap = (4 * s) / CE, c = (4 * s) % CE;
       const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + ((f >> 1) * IW + (f & 1) * 16) * CP], bw[s][0], acc[f], 0, 0, 0);
+      for (int f = 0; f < NFR; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + (TW == 32 ? ((f >> 1) * IW + (f & 1) * 16) : f * IW) * CP], bw[s][0], acc[f], 0, 0, 0);
     }
     const int col = l15;
     const float bv = p.bias[col];
     const bool cok = col < p.Cout;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int oy = ty0 + wave * 2 + (f >> 1);
+    for (int f = 0; f < NFR; ++f) {
+      const int oy = ty0 + wave * 2 + (TW == 32 ? (f >> 1) : f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ox = tx0 + (f & 1) * 16 + lq * 4 + r;
+        const int ox = tx0 + (TW == 32 ? (f & 1) * 16 : 0) + lq * 4 + r;
         float v = apply_act(acc[f][r] + bv, p.act);
         if (BF16) v = bf16_round(v);
         const bool ok = cok && oy < p.H && ox < p.W;

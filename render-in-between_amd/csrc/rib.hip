@@ -403,7 +403,7 @@ struct Op {
   InAddParams ap; PRef a_t1, a_sc1, a_sh1, a_ts, a_scs, a_shs, a_x, a_out;
   // pack
   PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
-  LowcParams lc; PRef lc_s0, lc_s1, lc_s2, lc_w, lc_bias, lc_y, lc_stat; int lowc_ce = 0, lowc_ncol = 0;
+  LowcParams lc; PRef lc_s0, lc_s1, lc_s2, lc_w, lc_bias, lc_y, lc_stat; int lowc_ce = 0, lowc_ncol = 0, lowc_tw = 32;
   // Winograd transforms
   WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v;
   WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
@@ -520,15 +520,20 @@ const ConvDef& conv_of(const rib_handle* h, const std::string& name) {
 static bool lowc_instantiated(int ce, int ncol) {
   return (ce == 6 && ncol == 64) || (ce == 10 && ncol == 32) || (ce == 22 && ncol == 32) || (ce == 24 && ncol == 16);
 }
-template <int CE, int NCOL> static void launch_lowc_t(bool bf16, dim3 grid, hipStream_t st, const LowcParams& p) {
-  if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false>), grid, dim3(256), 0, st, p);
+template <int CE, int NCOL> static void launch_lowc_t(bool bf16, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (tw == 16) {
+    if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false, 16>), grid, dim3(256), 0, st, p);
+  } else {
+    if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true, 32>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false, 32>), grid, dim3(256), 0, st, p);
+  }
 }
-static void launch_lowc(int ce, int ncol, bool bf16, dim3 grid, hipStream_t st, const LowcParams& p) {
-  if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(bf16, grid, st, p);
-  else if (ce == 10 && ncol == 32) launch_lowc_t<10, 32>(bf16, grid, st, p);
-  else if (ce == 22 && ncol == 32) launch_lowc_t<22, 32>(bf16, grid, st, p);
-  else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(bf16, grid, st, p);
+static void launch_lowc(int ce, int ncol, bool bf16, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(bf16, tw, grid, st, p);
+  else if (ce == 10 && ncol == 32) launch_lowc_t<10, 32>(bf16, tw, grid, st, p);
+  else if (ce == 22 && ncol == 32) launch_lowc_t<22, 32>(bf16, tw, grid, st, p);
+  else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(bf16, tw, grid, st, p);
 }
 
 void assign_weight_layout(rib_handle* h) {
@@ -578,10 +583,11 @@ void assign_weight_layout(rib_handle* h) {
       c.zero_off = take(c.coutp);
     }
   }
-  // first-layer convolutions over the caller's tensors (k_conv_lowc, every precision mode): filter in real-channel K order
+  // first-layer convolutions over the caller's tensors (k_conv_lowc, fp32 arithmetic): filter in real-channel K order.  Not
+  // with bf16 storage: there the packed bf16 copy + bf16 matrix cores are faster (679 vs 672 frames/s, A/B)
   for (auto& c : h->convs) {
     c.wl_off = 0; c.lowc_ce = c.lowc_ncol = 0;
-    if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || getenv("RIB_NO_LOWC")) continue;
+    if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || h->compute_bf16 || getenv("RIB_NO_LOWC")) continue;
     const int ncol = c.cout <= 16 ? 16 : c.coutp;      // (coutp is a multiple of 32; the 16-column instantiation serves Cout <= 16)
     const int ce = ncol == 16 ? (c.cin + 3) / 4 * 4 : (c.cin + 1) / 2 * 2;
     if (!lowc_instantiated(ce, ncol)) continue;
@@ -909,7 +915,12 @@ struct Builder {
     p.c0 = a.in.uc[0]; p.c1 = a.in.uc[1]; p.c2 = a.in.uc[2];
     p.H = H; p.W = W; p.yC = a.out.Cp; p.yoff = a.yoff; p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
     p.act = a.act; p.CoutPad = c.coutp;
-    p.tilesX = (W + 31) / 32; p.tilesY = (H + 7) / 8;
+    // 8x16 tiles (2048 workgroups at 512x512: two rounds, whose gather / MFMA / store phases overlap) win where the layer is
+    // store-bound and has no statistics (conv_first 44.6 -> 38.4 us); with statistics the finalize of twice the partials
+    // eats the gain (down_lbl.0 -3 +3 us) and the 16-column layer loses (29.5 -> 32.7)
+    const int tw = getenv("RIB_LOWC_TW") ? (atoi(getenv("RIB_LOWC_TW")) == 16 ? 16 : 32) : ((c.lowc_ncol == 64 && !a.want_stats) ? 16 : 32);
+    op.lowc_tw = tw;
+    p.tilesX = (W + tw - 1) / tw; p.tilesY = (H + 7) / 8;
     if (p.Cout > c.lowc_ncol || c.cout > c.lowc_ncol) { error = opname + ": more output columns than the k_conv_lowc instantiation has"; return false; }
     op.lc_s0 = US(a.in.usrc[0]); if (p.c1) op.lc_s1 = US(a.in.usrc[1]); if (p.c2) op.lc_s2 = US(a.in.usrc[2]);
     op.lc_w = WT(c.wl_off); op.lc_bias = WT(c.b_off); op.lc_y = WS(a.out.off);
@@ -1640,7 +1651,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         p.s0 = R.get<const float>(op.lc_s0); p.s1 = R.get<const float>(op.lc_s1); p.s2 = R.get<const float>(op.lc_s2);
         p.w = R.get<const float>(op.lc_w); p.bias = R.get<const float>(op.lc_bias); p.y = R.get<float>(op.lc_y);
         p.stat_part = R.get<double>(op.lc_stat);
-        launch_lowc(op.lowc_ce, op.lowc_ncol, bf16, op.grid, st, p);
+        launch_lowc(op.lowc_ce, op.lowc_ncol, bf16, op.lowc_tw, op.grid, st, p);
       } break;
       case OP_PACK: {
         PackParams p = op.kp;
@@ -2304,8 +2315,8 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
              op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
   else if (op.kind == OP_LOWC)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|lowc (caller's NCHW tensors, K = 9 x %d real channels) 8x32 tile, %d columns|%.0f", op.name.c_str(), op.kclass,
-             op.grid.x, op.grid.y, op.grid.z, op.lowc_ce, op.lowc_ncol, op.flops);
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|lowc (caller's NCHW tensors, K = 9 x %d real channels) 8x%d tile, %d columns|%.0f", op.name.c_str(), op.kclass,
+             op.grid.x, op.grid.y, op.grid.z, op.lowc_ce, op.lowc_tw, op.lowc_ncol, op.flops);
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;

@@ -797,6 +797,16 @@ def test_first_layers_read_the_callers_tensors_in_place(monkeypatch):
         oi, om = R(label, None, fake, prev)
         assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL, (B, H, W)
         del G2
+        for tw in ("16", "32"):                      # both tile shapes of every instantiation (the plan mixes them by layer)
+            monkeypatch.delenv("RIB_NO_LOWC", raising=False)
+            monkeypatch.setenv("RIB_LOWC_TW", tw)
+            G3 = rib.Generator(rib.hsm_gen_config()).eval(); G3.load_state_dict(sd)
+            assert all(("8x%s tile" % tw) in o["tile"] for o in G3.launch_info(B, H, W) if o["tile"].startswith("lowc"))
+            i3, m3 = G3(label, None, fake, prev)
+            torch.cuda.synchronize()
+            assert max(float((i1 - i3).abs().max()), float((m1 - m3).abs().max())) < 5e-5, (B, H, W, tw)
+            del G3
+        monkeypatch.delenv("RIB_LOWC_TW", raising=False)
         if (H, W) == (48, 80):
             # chain: frame t of the segment == the per-frame call on (label_t, dain_t, fused_{t-1})
             monkeypatch.delenv("RIB_NO_LOWC", raising=False)
