@@ -232,3 +232,30 @@ def test_cubic_resize_follows_the_opencv_definition():
     from PIL import Image
     pil = np.asarray(Image.fromarray(st).resize((16, 16), Image.BICUBIC))
     assert 60 < pil.mean() < 110
+
+
+def test_load_image_resizes_like_the_reference_transform(tmp_path):
+    """`Evaluator.load_image` on a file that is not at the model size: the OpenCV-style cubic resize (default) equals the
+    scalar restatement followed by ToTensor + Normalize(.5, .5); `resize="pil"` keeps PIL's bicubic; both report the
+    original size (the keypoints are scaled by it)."""
+    from PIL import Image
+    from oracle import resize_ref
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, size=(45, 70, 3), dtype=np.uint8)
+    path = str(tmp_path / "k.png")
+    Image.fromarray(a).save(path)
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48, gauss_sigma=5, skeleton_thres=0.001, foot_thres=0.001)
+    E = ev.Evaluator(cfg, label_fn=oracle_labels)
+    t, size0 = E.load_image(path)
+    assert size0 == (70, 45) and tuple(t.shape) == (3, 32, 48)
+    want = resize_ref.resize_cubic_u8(a, 48, 32).astype(np.float32) / 255.0
+    assert torch.equal(t, torch.from_numpy((want - 0.5) / 0.5).permute(2, 0, 1).contiguous())
+    u8, _ = E.load_image_u8(path)
+    assert np.array_equal(u8.numpy(), resize_ref.resize_cubic_u8(a, 48, 32))
+    Ep = ev.Evaluator(cfg, label_fn=oracle_labels, resize="pil")
+    tp, _ = Ep.load_image(path)
+    pil = np.asarray(Image.fromarray(a).resize((48, 32), Image.BICUBIC), dtype=np.float32) / 255.0
+    assert torch.equal(tp, torch.from_numpy((pil - 0.5) / 0.5).permute(2, 0, 1).contiguous())
+    assert not torch.equal(t, tp)
+    with pytest.raises(ValueError):
+        ev.Evaluator(cfg, resize="area")

@@ -7,8 +7,10 @@ import torch
 import render_in_between_amd as rib
 from render_in_between_amd import synth
 
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"          # f32 | bf16 | f32x3
 cfg = rib.hsm_gen_config(); spec = rib.GenSpec.from_cfg(cfg)
-G = rib.Generator(cfg).eval(); G.load_state_dict(synth.make_state_dict(spec, 0))
+G = rib.Generator(cfg, compute_dtype=DTYPE).eval(); G.load_state_dict(synth.make_state_dict(spec, 0))
+print("dtype", DTYPE)
 label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, 1, 512, 512, 0)]
 
 
