@@ -2151,14 +2151,20 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   }
   // ---- this lane's filter fragments (registers; after the staging so that its 30 values in flight are dead: 116 instead
   // of 198 VGPRs on the 22-channel layers) ----
-  float bw[S][NF];
-  {
-    const float* pw = N16 ? p.w + (lane >> 4) * 16 + (lane & 15) : p.w + (lane >> 5) * NCOL + (lane & 31);
+  // More than 64 of them (the 22-channel layers: 99) are loaded in two halves: 99 + 32 accumulators is 3 waves per SIMD,
+  // i.e. 768 workgroup slots for the 1024 tiles of a 512x512 frame - a second round a third full; ~50 + 32 fits 4.
+  constexpr int HV = (!N16 && S * NF > 64) ? 2 : 1;
+  constexpr int SH = (S + HV - 1) / HV;
+  float bw[SH][NF];
+  const float* pw = N16 ? p.w + (lane >> 4) * 16 + (lane & 15) : p.w + (lane >> 5) * NCOL + (lane & 31);
+  auto load_b = [&](int h) {
 #pragma unroll
-    for (int s = 0; s < S; ++s)
+    for (int s = 0; s < SH; ++s)
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bw[s][nf] = pw[s * KG * NCOL + nf * 32];
-  }
+      for (int nf = 0; nf < NF; ++nf)
+        if (h * SH + s < S) bw[s][nf] = pw[(h * SH + s) * KG * NCOL + nf * 32];
+  };
+  load_b(0);
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;                      // this lane's column: sum and sum of squares over its valid pixels
   if constexpr (!N16) {
@@ -2173,14 +2179,21 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
     // window origin of this lane's pixel: (row 2*wave [+ mf], x = li) or, 16 wide, (row 2*wave + li/16, x = li%16); k parity lh
     const float* pa = sA + (TW == 32 ? ((wave * 2) * IW + li) : ((wave * 2 + (li >> 4)) * IW + (li & 15))) * CP + lh;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int tap = (2 * s) / CE, c = (2 * s) % CE;
-      const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
+    for (int h = 0; h < HV; ++h) {
+      if (h > 0) load_b(h);
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const float a = pa[off + mf * IW * CP];
+      for (int sl = 0; sl < SH; ++sl) {
+        const int s = h * SH + sl;
+        if (s < S) {
+          const int tap = (2 * s) / CE, c = (2 * s) % CE;
+          const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s][nf], acc[mf][nf], 0, 0, 0);
+          for (int mf = 0; mf < MF; ++mf) {
+            const float a = pa[off + mf * IW * CP];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[sl][nf], acc[mf][nf], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
