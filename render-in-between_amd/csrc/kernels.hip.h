@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(!SPADE || (NF % 2 == 0 && NF > 0), "SPADE needs gamma/beta fragment pairs");
+  static_assert(!SPADE || (NF % 2 == 0 && NF > 0) || (NF == 1 && PREC == PREC_F32 && KW == 1), "SPADE needs gamma/beta fragment pairs, or ONE fragment [gamma(16) | beta(16)] (fp32)");
   static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0 && PREC == PREC_F32), "16-column path: 8x16-style tiles only, fp32");
   static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && (TB == 1 || TB == 4) && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
   constexpr int PH = G::PH;
@@ -1132,6 +1132,55 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
           double* dst = p.stat_part + (((size_t)n * (p.tilesX * p.tilesY) + tile) * 2) * p.CoutPad;
           dst[col] = a1;
           dst[p.CoutPad + col] = a2;
+        }
+      }
+    }
+  } else if constexpr (NF == 1) {
+    // ONE fragment per wave: columns [gamma(16) | beta(16)] of 16 consecutive virtual channels (layers that modulate 16
+    // channels in all: the pair layout would multiply two half-empty fragments).  A lane holds gamma (li < 16) or beta
+    // (li >= 16) of channel li % 16 for the fragment's 16 rows; the halves exchange them with one shuffle per row and then
+    // each finishes 8 rows: gamma lanes rows 0-7, beta lanes rows 8-15.
+    const int hb = li >> 4, c16 = li & 15;
+    const int colg = n0 + wn * 32 + c16;                        // gamma column in w / bias; beta = + 16
+    const int v = (n0 / 2) + wn * 16 + c16;                     // virtual channel
+    const bool vvalid = v < p.nsets * p.C;
+    const int set = (vvalid && v >= p.C) ? 1 : 0;
+    const int c = v - set * p.C;
+    float bg = 0.f, bb = 0.f, sc = 0.f, sh = 0.f;
+    if (vvalid) {
+      bg = p.bias[colg]; bb = p.bias[colg + 16];
+      if (p.m_part) { sc = s_stat[v - n0 / 2]; sh = s_stat[G::BN / 2 + v - n0 / 2]; }
+      else { sc = p.m_scale[(size_t)n * p.m_ld + c]; sh = p.m_shift[(size_t)n * p.m_ld + c]; }
+    }
+    float* yout = set ? p.ys1 : p.ys0;
+    const int act = set ? p.act1 : p.act0;
+    const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float xr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = hb * 8 + k;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
+        const int ox = min(tx0 + row % FRW, p.Wout - 1);
+        const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+        xr[k] = ld_act<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float lo = acc[mf][0][k], hi = acc[mf][0][8 + k];
+        const float olo = __shfl_xor(lo, 16), ohi = __shfl_xor(hi, 16);
+        const float gamma = (hb ? ohi : lo) + bg;               // gamma lanes own row k, beta lanes fetch row 8 + k's gamma
+        const float beta = (hb ? hi : olo) + bb;
+        const int r = hb * 8 + k;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+        const int ox = tx0 + row % FRW;
+        if (vvalid && oy < p.Hout && ox < p.Wout) {
+          float o = (xr[k] * sc + sh) * (1.f + gamma) + beta;
+          o = apply_act(o, act);
+          st_act<BF16>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
         }
       }
     }

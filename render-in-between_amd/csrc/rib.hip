@@ -127,6 +127,9 @@ struct SpadeGroup {   // one SPADE launch: 1 or 2 modulations sharing the normal
   size_t w_off = 0, b_off = 0;
   size_t w16_off = 0; // bf16 copy of the gamma/beta filters (bf16 storage mode)
   int npad = 0;       // virtual columns (multiple of 64)
+  // 16 modulated channels in all (C = 16, one set): a second copy in [gamma(16) | beta(16)] order, one 32-column
+  // fragment instead of two half-empty ones (fp32 SPADE variants with NF = 1)
+  size_t w1_off = 0, b1_off = 0;
 };
 
 struct Cfg {
@@ -317,6 +320,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
     const Variant& v = kVariants[i];
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     if (v.NF == 0 && !allow_n16) continue;
+    if (v.SPADE && v.NF == 1) continue;      // 16-channel SPADE layout: chosen explicitly (Builder::spade)
     if (v.BF16 != bf16) continue;   // (bf16 carries the handle's precision mode)
     const int BK = v.BK;
     // in-workgroup split-K only where the tile grid alone cannot fill the chip
@@ -581,6 +585,13 @@ void assign_weight_layout(rib_handle* h) {
       c.wu_off = take((size_t)16 * c.coutp * c.cinp);
       c.wu4_off = take((size_t)36 * c.coutp * c.cinp);
       c.zero_off = take(c.coutp);
+    }
+  }
+  for (auto& sg : h->spades) {
+    sg.w1_off = sg.b1_off = 0;
+    if (h->prec() == PREC_F32 && sg.nsets * sg.Cp == 16 && !getenv("RIB_NO_SPADE16")) {
+      sg.w1_off = take((size_t)32 * h->padc(sg.cond));
+      sg.b1_off = take(32);
     }
   }
   // first-layer convolutions over the caller's tensors (k_conv_lowc, fp32 arithmetic): filter in real-channel K order.  Not
@@ -1044,6 +1055,11 @@ struct Builder {
     // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
     // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
     const Variant* v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    if (sg.w1_off)      // 16 modulated channels: the one-fragment layout halves the matrix work (first fitting NF = 1 variant)
+      for (int i = 0; i < kNumVariants; ++i) {
+        const Variant& t = kVariants[i];
+        if (t.SPADE && t.NF == 1 && t.BF16 == h->prec() && t.KW == 1 && t.TB == 1 && cond.Cp % t.BK == 0) { v = &t; break; }
+      }
     Choice uf;   // unfused candidate
     const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
     if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
@@ -1053,7 +1069,8 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1)) {
+        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1) ||
+            (tv.SPADE && tv.NF == 1 && !sg.w1_off)) {
           error = key + ": tuned SPADE choice does not fit"; return false;
         }
         if (tv.SPADE) { v = &tv; unfused = false; }
@@ -1096,12 +1113,15 @@ struct Builder {
     IgemmParams& p = op.ip;
     memset(&p, 0, sizeof p);
     p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
-    p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout;
+    const bool one_frag = v->NF == 1;      // [gamma(16) | beta(16)] layout
+    const int ncols = one_frag ? 32 : sg.npad;
+    p.CoutPad = ncols; p.Hout = Hout; p.Wout = Wout;
     p.tilesX = (Wout + v->TW() - 1) / v->TW(); p.tilesY = (Hout + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
     p.ksplit = 1;
     p.xmC = x.Cp; p.xm_ups = x_ups ? 1 : 0; p.m_ld = nx.ld; p.C = sg.Cp; p.nsets = sg.nsets;
     p.act0 = act0 ? ACT_LRELU : ACT_NONE; p.act1 = ACT_NONE;
     op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off);
+    if (one_frag) { op.w = WT(sg.w1_off); op.bias = WT(sg.b1_off); }
     op.xm = WS(x.off);
     if (has_partials(nx) && !nx.pend->affine && sg.Cp <= nx.pend->Cs) {   // consumer-side finalize in the SPADE epilogue
       const PendingStats& ps = *nx.pend;
@@ -1111,7 +1131,7 @@ struct Builder {
       op.m_scale = WS(nx.sc); op.m_shift = WS(nx.sh);
     }
     op.ys0 = WS(ys0->off); if (sg.nsets == 2) op.ys1 = WS(ys1->off);
-    op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + v->BN() - 1) / v->BN(), B);
+    op.grid = dim3(p.tilesX * p.tilesY, (ncols + v->BN() - 1) / v->BN(), B);
     op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
     P->flops[RIB_KC_SPADE] += op.flops;
     push(op);
@@ -1861,6 +1881,14 @@ int rib_finalize_weights(rib_handle* h) {
         }
         blob[sg.b_off + colg] = b[ch];
         blob[sg.b_off + colb] = b[sg.C + ch];
+        if (sg.w1_off) {   // [gamma(16) | beta(16)]: v < 16
+          for (int k = 0; k < sg.cond; ++k) {
+            blob[sg.w1_off + (size_t)v * condp + k] = w[(size_t)ch * sg.cond + k];
+            blob[sg.w1_off + (size_t)(16 + v) * condp + k] = w[(size_t)(sg.C + ch) * sg.cond + k];
+          }
+          blob[sg.b1_off + v] = b[ch];
+          blob[sg.b1_off + 16 + v] = b[sg.C + ch];
+        }
       }
     }
   }
