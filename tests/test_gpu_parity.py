@@ -822,3 +822,34 @@ def test_first_layers_read_the_callers_tensors_in_place(monkeypatch):
                 p = f.clone()
         del G1
     monkeypatch.delenv("RIB_NO_LOWC", raising=False)
+
+
+def test_sixteen_channel_spade_layout_agrees_with_the_pair_layout(monkeypatch):
+    """down_0.1 / up_0.1 modulate 16 channels: by default one [gamma(16) | beta(16)] MFMA fragment per wave (k_igemm<SPADE,
+    NF = 1>, the halves exchange rows with shuffles); with RIB_NO_SPADE16 the pair layout every other SPADE uses.  Same
+    frame, and the modulated tensors (taps `.y1`) agree with the oracle's."""
+    spec, sd, _ = build("full", 0)
+    R = oracle(spec, sd)
+    for (B, H, W, seed) in ((1, 96, 96, 21), (2, 48, 80, 22), (1, 176, 112, 23)):      # (maps of <= 4096 pixels run GEMM + modulate instead)
+        label, fake, prev = synth.make_inputs(spec, B, H, W, seed)
+        monkeypatch.delenv("RIB_NO_SPADE16", raising=False)
+        G1 = rib.Generator(rib.hsm_gen_config()).eval(); G1.load_state_dict(sd)
+        one = [o for o in G1.launch_info(B, H, W) if o["name"] in ("down_0.1.spade", "up_0.1.spade")]
+        assert len(one) == 2 and all("BN 32" in o["tile"] for o in one), one
+        if (H, W) == (96, 96):
+            G1.enable_taps()
+        i1, m1 = [t.clone() for t in G1(label, None, fake, prev)]
+        if (H, W) == (96, 96):
+            taps = G1.read_taps(B, H, W)
+            otaps = {}
+            R(label, None, fake, prev, taps=otaps)
+            for k in ("down_0.y1", "up_0.y1", "down_0", "up_0"):
+                assert float((taps[k] - otaps[k]).abs().max()) / max(1.0, float(otaps[k].abs().max())) <= 2e-5, k
+        monkeypatch.setenv("RIB_NO_SPADE16", "1")
+        G2 = rib.Generator(rib.hsm_gen_config()).eval(); G2.load_state_dict(sd)
+        assert all("BN 32" not in o["tile"] for o in G2.launch_info(B, H, W) if o["name"] in ("down_0.1.spade", "up_0.1.spade"))
+        i2, m2 = G2(label, None, fake, prev)
+        torch.cuda.synchronize()
+        assert max(float((i1 - i2).abs().max()), float((m1 - m2).abs().max())) < 2e-5, (B, H, W)
+        del G1, G2
+    monkeypatch.delenv("RIB_NO_SPADE16", raising=False)
