@@ -380,7 +380,6 @@ struct Op {
   int kclass;
   std::string name;
   int stream = ST_MAIN;
-  bool spade_side = false;   // a hoisted gamma/beta GEMM: runs on the handle's side stream between the plan's fork and join
   std::vector<int> wait_ev;   // plan events this op waits for (on its stream) before it launches
   int record_ev = -1;         // plan event recorded on its stream after it launches
   // igemm
@@ -452,9 +451,6 @@ struct Plan {
   LabelSlots ls;
   int B, H, W;
   int num_events = 0;
-  // hoisted SPADE GEMMs (contiguous ops side_first .. side_last on the side stream); the first main-stream op that reads
-  // one of their slabs waits for the join
-  int side_first = -1, side_last = -1, side_join_before = -1;
   size_t ws_bytes = 0;
   size_t ws_virtual = 0;   // bytes before lifetime-based reuse (one range per buffer)
   std::vector<Op> ops;
@@ -494,8 +490,6 @@ struct rib_handle {
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> stream_pool;
   bool use_streams = false;
-  hipStream_t spade_stream = nullptr;   // side stream of the hoisted SPADE GEMMs (RIB_NO_SPADE_STREAM: none)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   bool profiling = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -1050,75 +1044,6 @@ struct Builder {
   }
 
   // ---- SPADE launch: ys0 (= lrelu(mod0(x))), optional ys1 (= mods(x), no activation) -------
-  // fused or unfused?  (shared by spade() and the hoisting pass)
-  bool spade_decide(const SpadeGroup& sg, const std::string& key, const Act& cond, int Hout, int Wout,
-                    const Variant*& v, Choice& uf, bool& unfused) {
-    // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
-    // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
-    // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
-    v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
-    if (sg.w1_off)      // 16 modulated channels: the one-fragment layout halves the matrix work (first fitting NF = 1 variant)
-      for (int i = 0; i < kNumVariants; ++i) {
-        const Variant& t = kVariants[i];
-        if (t.SPADE && t.NF == 1 && t.BF16 == h->prec() && t.KW == 1 && t.TB == 1 && cond.Cp % t.BK == 0) { v = &t; break; }
-      }
-    const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
-    if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
-    unfused = small_map && uf.v != nullptr;
-    auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
-    if (it != h->choices.end()) {
-      const Variant& tv = kVariants[it->second.first];
-      const int ts = it->second.second;
-      if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1) ||
-          (tv.SPADE && tv.NF == 1 && !sg.w1_off)) {
-        error = key + ": tuned SPADE choice does not fit"; return false;
-      }
-      if (tv.SPADE) { v = &tv; unfused = false; }
-      else { uf.v = &tv; uf.ksplit = ts; unfused = true; }
-    }
-    if (!unfused && !v) { error = "no SPADE variant"; return false; }
-    return true;
-  }
-
-  // the gamma/beta GEMM of an unfused SPADE: a (split-K) 1x1 convolution of the condition map into partial slabs
-  size_t emit_spade_gemm(const SpadeGroup& sg, const std::string& key, const Act& cond, int Hout, int Wout, const Choice& uf, bool side) {
-    const Variant* cv = uf.v; const int S = uf.ksplit;
-    const size_t slab_off = alloc((size_t)S * B * Hout * Wout * sg.npad * sizeof(float));
-    Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = cv; op.spade_side = side;
-    IgemmParams& p = op.ip;
-    memset(&p, 0, sizeof p);
-    p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
-    p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
-    p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
-    op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
-    op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
-    op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
-    P->flops[RIB_KC_SPADE] += op.flops;
-    push(op);
-    return slab_off;
-  }
-
-  // Hoisting: the gamma/beta GEMM of a SPADE depends on the condition map only, which is complete once the condition
-  // encoder has run - long before the deep blocks need it.  The GEMMs of the SPADEs that run unfused (the <= 64x64 maps: ten
-  // launches of 256-512 workgroups, ~130 us) are emitted right after the encoder on the handle's side stream, where they
-  // fill the ramps and tails of the first blocks' launches; the main stream joins before the first modulate that reads one.
-  struct Hoisted { size_t slab_off; int S; };
-  std::map<std::string, Hoisted> hoisted;
-  bool hoist_spade_gemm(const std::string& key, const Act& cond, int Hout, int Wout) {
-    auto si = h->spade_index.find(key);
-    if (si == h->spade_index.end()) return true;
-    const SpadeGroup& sg = h->spades[si->second];
-    if (cond.H != Hout || cond.W != Wout || cond.Cp != h->padc(sg.cond) || cond.Cp % 32 != 0) return true;   // spade() reports it
-    const Variant* v = nullptr; Choice uf; bool unfused = false;
-    if (!spade_decide(sg, key, cond, Hout, Wout, v, uf, unfused)) return false;
-    if (!unfused) return true;
-    if (P->side_first < 0) P->side_first = (int)P->ops.size();
-    const size_t slab = emit_spade_gemm(sg, key, cond, Hout, Wout, uf, true);
-    P->side_last = (int)P->ops.size() - 1;
-    hoisted[key] = Hoisted{slab, uf.ksplit};
-    return true;
-  }
-
   bool spade(const std::string& key, const Act& cond, const Act& x, bool x_ups, const Norm& nx,
              Act* ys0, Act* ys1, bool act0) {
     const SpadeGroup& sg = h->spades[h->spade_index.at(key)];
@@ -1126,20 +1051,50 @@ struct Builder {
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
     if (cond.Cp != h->padc(sg.cond) || cond.Cp % 32 != 0) { error = fmt("%s: cond channels %d unsupported (need a multiple of 32)", key.c_str(), cond.Cp); return false; }
     if (x.Cp != sg.Cp) { error = fmt("%s: x channels %d != %d", key.c_str(), x.Cp, sg.Cp); return false; }
-    const Variant* v = nullptr; Choice uf; bool unfused = false;
-    auto hit = hoisted.find(key);
-    if (hit != hoisted.end()) { unfused = true; uf.ksplit = hit->second.S; }
-    else if (!spade_decide(sg, key, cond, Hout, Wout, v, uf, unfused)) return false;
+    // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
+    // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
+    // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
+    const Variant* v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    if (sg.w1_off)      // 16 modulated channels: the one-fragment layout halves the matrix work (first fitting NF = 1 variant)
+      for (int i = 0; i < kNumVariants; ++i) {
+        const Variant& t = kVariants[i];
+        if (t.SPADE && t.NF == 1 && t.BF16 == h->prec() && t.KW == 1 && t.TB == 1 && cond.Cp % t.BK == 0) { v = &t; break; }
+      }
+    Choice uf;   // unfused candidate
+    const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
+    if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
+    bool unfused = small_map && uf.v != nullptr;
+    {
+      auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
+      if (it != h->choices.end()) {
+        const Variant& tv = kVariants[it->second.first];
+        const int ts = it->second.second;
+        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1) ||
+            (tv.SPADE && tv.NF == 1 && !sg.w1_off)) {
+          error = key + ": tuned SPADE choice does not fit"; return false;
+        }
+        if (tv.SPADE) { v = &tv; unfused = false; }
+        else { uf.v = &tv; uf.ksplit = ts; unfused = true; }
+      }
+    }
+    if (!unfused && !v) { error = "no SPADE variant"; return false; }
     if (unfused) {
       materialize(nx, key + ".spade");
       *ys0 = act(sg.C, Hout, Wout);
       if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
-      const int S = uf.ksplit;
-      size_t slab_off;
-      if (hit != hoisted.end()) {
-        slab_off = hit->second.slab_off;
-        if (P->side_join_before < 0) P->side_join_before = (int)P->ops.size();     // the modulate pushed next
-      } else slab_off = emit_spade_gemm(sg, key, cond, Hout, Wout, uf, false);
+      const Variant* cv = uf.v; const int S = uf.ksplit;
+      const size_t slab_off = alloc((size_t)S * B * Hout * Wout * sg.npad * sizeof(float));
+      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = cv;
+      IgemmParams& p = op.ip;
+      memset(&p, 0, sizeof p);
+      p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
+      p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
+      p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+      op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
+      op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
+      op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
+      P->flops[RIB_KC_SPADE] += op.flops;
+      push(op);
       Op mo; mo.kind = OP_MODULATE; mo.kclass = RIB_KC_ELTWISE; mo.name = key + ".spade.modulate";
       memset(&mo.mp, 0, sizeof mo.mp);
       mo.mp.ksplit = S; mo.mp.B = B; mo.mp.npad = sg.npad; mo.mp.xmC = x.Cp; mo.mp.xm_ups = x_ups ? 1 : 0;
@@ -1407,20 +1362,6 @@ struct Builder {
       }
     }
 
-    // ---- hoisted gamma/beta GEMMs of the SPADEs that run unfused (see hoist_spade_gemm) ----
-    if (!h->use_streams && !getenv("RIB_LBL_AT") && !getenv("RIB_NO_SPADE_HOIST")) {
-      const int jres_h = std::min(c.emb_down, D + 1);
-      for (int i = 0; i <= D; ++i)
-        for (const char* w : {".0", ".1"})
-          if (!hoist_spade_gemm("down_" + std::to_string(i) + w, cond[std::min(c.emb_down, i)], H >> i, W >> i)) return false;
-      for (int i = 0; i < g.num_res_blocks(); ++i)
-        for (const char* w : {".0", ".1"})
-          if (!hoist_spade_gemm("res_" + std::to_string(i) + w, cond[jres_h], H >> D, W >> D)) return false;
-      for (int i = D; i >= 0; --i)
-        for (const char* w : {".0", ".1"})
-          if (!hoist_spade_gemm("up_" + std::to_string(i) + w, cond[std::min(i, c.emb_down)], H >> i, W >> i)) return false;
-    }
-
     // ---- label branch of the mask network (depends only on the label map): side stream ----
     const std::string m = "flow_network_temp";
     const int chm = g.mask_nf(c.mask_down);
@@ -1632,22 +1573,10 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
       h->events.push_back(e);
     }
   const bool bf16 = h->compute_bf16;
-  // hoisted SPADE GEMMs: fork when the plan reaches them (the condition maps are complete), join before their first reader
-  const bool side = !multi && !single_stream && h->spade_stream != nullptr && P->side_first >= 0;
-  int op_index = -1;
   for (Op& op : P->ops) {
-    ++op_index;
     if (skip_label_ops && op.label_only) continue;     // done for the whole chain by the labels-only plan
     // in single-stream mode the plan order is already a valid topological order
     hipStream_t st = (multi && op.stream != ST_MAIN) ? h->side[op.stream] : caller;
-    if (side) {
-      if (op_index == P->side_first) {
-        HIP_TRY(h, hipEventRecord(h->ev_fork, caller));
-        HIP_TRY(h, hipStreamWaitEvent(h->spade_stream, h->ev_fork, 0));
-      }
-      if (op.spade_side) st = h->spade_stream;
-      if (op_index == P->side_join_before) HIP_TRY(h, hipStreamWaitEvent(caller, h->ev_join, 0));
-    }
     if (multi)
       for (int ev : op.wait_ev) HIP_TRY(h, hipStreamWaitEvent(st, h->events[ev], 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1757,7 +1686,6 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
       h->prof_events.push_back({op.kclass, {e0, e1}});
     }
     if (multi && op.record_ev >= 0) HIP_TRY(h, hipEventRecord(h->events[op.record_ev], st));
-    if (side && op_index == P->side_last) HIP_TRY(h, hipEventRecord(h->ev_join, h->spade_stream));
   }
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
@@ -1818,11 +1746,6 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
       }
       if (e == hipSuccess && a >= 0 && a < 6 && b >= 0 && b < 6) { h->side[ST_EMBED] = h->stream_pool[a]; h->side[ST_LABEL] = h->stream_pool[b]; h->use_streams = true; }
     } else h->use_streams = false;
-    if (e == hipSuccess && !h->use_streams && !getenv("RIB_NO_SPADE_STREAM")) {
-      e = hipStreamCreateWithFlags(&h->spade_stream, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-    }
     if (e != hipSuccess) { g_create_error = fmt("rib_create: device %d: %s", device, hipGetErrorString(e)); return RIB_ERR_HIP; }
   }
   *out = h.release();
@@ -1833,9 +1756,6 @@ void rib_destroy(rib_handle* h) {
   if (!h) return;
   if (h->d_blob) (void)hipFree(h->d_blob);
   for (hipStream_t st : h->stream_pool) (void)hipStreamDestroy(st);
-  if (h->spade_stream) (void)hipStreamDestroy(h->spade_stream);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
   delete h;
