@@ -263,7 +263,7 @@ def main():
         # 2 launches, 0.5 GFLOP) run as k_conv_small on the vector ALUs.  "algorithmic" = nine-tap 2*MAC count of
         # SURVEY 8(d); the three upsample convolutions (phase decomposition) and the Winograd-domain GEMMs of the deep 3x3
         # layers execute 4/9 of theirs: `executed_*` below counts what the matrix cores actually do
-        "kernel": "convolution class: k_igemm, %s MFMA implicit GEMM (%d launches/step incl. 2 k_conv_small heads)" % (args.dtype, int(prof["igemm"]["launches"] / nprof)),
+        "kernel": "convolution class: k_igemm (%s MFMA implicit GEMM, incl. the Winograd-domain batched GEMMs), k_conv_lowc (first layers), k_conv_head (2 heads): %d launches/step" % (args.dtype, int(prof["igemm"]["launches"] / nprof)),
         "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
         "frac": conv_tflops / peak,
         "avg_launch_us": conv_ms * 1e3 / max(1.0, prof["igemm"]["launches"] / nprof),
