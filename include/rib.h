@@ -9,11 +9,8 @@
  *
  * Ownership: the caller owns every tensor and the workspace; a handle owns only the weight blob
  * and its launch plans.  A handle is bound to one device, is single-stream and not re-entrant
- * (one handle per GPU / process).  Work is ordered on the caller's stream: a forward may fork its two
- * independent branches (condition encoder, label branch of the mask network) onto handle-owned
- * side streams, but they start after everything already queued on the caller's stream and are
- * joined back into it before the outputs are written (opt-in with RIB_STREAMS=1: measured slower
- * than one stream at batch 1, so off by default).
+ * (one handle per GPU / process).  Every launch of an entry point is enqueued, in order, on the caller's
+ * stream; the handle owns no streams or events.
  * No entry point synchronises the device except rib_finalize_weights(), rib_read_tap() and
  * rib_profile_collect().
  *
@@ -95,13 +92,12 @@ int rib_import_weights(rib_handle* h, const void* src_device, size_t bytes, void
  *   RIB_DTYPE_BF16           BASELINE.json configs[2]: bf16 NHWC activations and bf16 filters in HBM and LDS, bf16
  *                            MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 InstanceNorm statistics
  *                            and SPADE arithmetic; the caller's tensors stay fp32 NCHW.
- *   RIB_DTYPE_F32X3          exploratory: fp32 storage; every MFMA operand is split into three bf16 terms (24
- *                            significant bits) and each 16-channel step runs six bf16 MFMAs - fp32-grade products at
- *                            3/8 of the matrix-core time.  Reported beside the fp32 mode, never instead of it.
- * The mode decides the weight-blob layout (bf16 / three-plane filter copies are appended): set it before
- * rib_finalize_weights / rib_import_weights (a handle that still holds the state-dict tensors re-folds by itself);
- * blobs are exchangeable only between handles of the same mode. ---- */
-enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1, RIB_DTYPE_F32X3 = 2 };
+ * The mode decides the weight-blob layout (bf16 filter copies are appended): set it before
+ * rib_finalize_weights / rib_import_weights (a handle that still holds the state-dict tensors re-folds by itself;
+ * tuned choices pinned with rib_set_choice are dropped, they name kernels of the other mode).  Blobs are
+ * exchangeable only between handles of the same mode and layout: the blob starts with a 64-byte header (magic,
+ * mode, size, a hash of the layout offsets) that rib_import_weights checks. ---- */
+enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1 };
 int rib_set_compute_dtype(rib_handle* h, int dtype);
 
 /* ---- forward: replaces  img, mask = net_G(label, label_prev, img_fake, img_prev)
@@ -185,11 +181,15 @@ int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* worksp
                  float* dst_nchw_device, void* hip_stream);
 
 /* ---- measurement: per-kernel-class device time with HIP events on the caller's stream ----
- * rib_profile_begin() makes subsequent rib_forward calls bracket every launch with events
- * (slower; never enable inside a timed region).  rib_profile_collect() synchronises and returns,
- * per class, the number of launches and total milliseconds since begin. */
+ * rib_profile_begin() makes subsequent forwards record ONE event in front of every launch and one behind the
+ * last (slower; never enable inside a timed region).  A launch is charged the time from its event to the next
+ * one, so the classes add up to the forward's time on the stream, dispatch gaps included.
+ * rib_profile_collect() synchronises and returns, per class, the number of launches and total milliseconds
+ * since begin.  RIB_KC_CONVAUX holds the launches that are part of computing a convolution of class
+ * RIB_KC_IGEMM but are not matrix-core kernels: the Winograd input / output transforms and the split-K slab
+ * sums - a convolution's time is IGEMM + CONVAUX. */
 enum { RIB_KC_IGEMM = 0, RIB_KC_SPADE = 1, RIB_KC_STATS = 2, RIB_KC_POOL = 3, RIB_KC_ELTWISE = 4,
-       RIB_KC_PACK = 5, RIB_KC_COUNT = 6 };
+       RIB_KC_PACK = 5, RIB_KC_CONVAUX = 6, RIB_KC_COUNT = 7 };
 int rib_profile_begin(rib_handle* h);
 int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms[RIB_KC_COUNT]);
 /* Algorithmic FLOPs (2*MAC) one rib_forward spends in class RIB_KC_IGEMM / RIB_KC_SPADE. */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RIB_LIBRARY: another build of the same C ABI (A/B measurements of two builds inside one gpurun call)
 LIB_PATH = os.environ.get("RIB_LIBRARY") or os.path.join(_HERE, "csrc", "librib.so")
 
-KC_NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
+KC_NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack", "conv_aux")
 
 
 class RibConfig(C.Structure):

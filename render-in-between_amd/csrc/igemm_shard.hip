@@ -60,7 +60,6 @@
 #define RIB_VSK(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VSK(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VB(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VB(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VBX(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VBX(RIB_F_TOUCH, __VA_ARGS__))
-#define RIB_VX3(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VX3(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_V1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_V1D(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VS1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VS1D(RIB_F_TOUCH, __VA_ARGS__))
 

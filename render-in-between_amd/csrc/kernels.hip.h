@@ -195,14 +195,13 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // Tile geometry: a 32-row MFMA fragment covers FRH x FRW pixels (FRH = 32 / FRW); a wave owns
 // MF fragments stacked vertically and NF 32-channel column fragments; the workgroup is
 // WM x WN waves (WM*WN == 4).  Spatial tile = (FRH*MF*WM) x FRW pixels, BN = 32*NF*WN channels.
-// PREC: 0 = fp32 (exact-fp32 matrix cores), 1 = bf16 storage + bf16 matrix cores, 2 = "f32x3": fp32 storage, every
-// operand split into three bf16 terms on the way into LDS (x = hi + mid + lo, each the bf16 rounding of what the
-// previous ones left: 24 significant bits) and six bf16 MFMAs per 16-channel step (hi*hi, hi*mid, mid*hi, mid*mid,
-// hi*lo, lo*hi; the dropped terms are below 2^-26 of the product) - fp32-grade products at 3/8 of the matrix time.
-enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F32X3 = 2 };
+// PREC: 0 = fp32 (exact-fp32 matrix cores), 1 = bf16 storage + bf16 matrix cores.  (Round 2's exploratory "f32x3" mode -
+// fp32 storage, operands split into three bf16 terms, six bf16 MFMAs per step - never beat fp32 once the deep layers ran
+// in the Winograd domain and was retired in round 3.)
+enum { PREC_F32 = 0, PREC_BF16 = 1 };
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, int PREC = 0>
 struct IgemmGeom {
-  static constexpr bool BF16 = PREC == PREC_BF16, X3 = PREC == PREC_F32X3;
+  static constexpr bool BF16 = PREC == PREC_BF16;
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
   static constexpr int TH = FRH * MF * WM;
@@ -214,7 +213,7 @@ struct IgemmGeom {
   static constexpr int IH = UPS ? (TH + 2) : ((TH - 1) * STRIDE + KS);
   static constexpr int IW = UPS ? (TW + 2) : ((TW - 1) * STRIDE + KS);
   static constexpr int EPS = BF16 ? 8 : 4;     // activation elements per 16-byte staging slot
-  static constexpr int KF = X3 ? 3 * BK / 2 : BK * 4 / EPS;   // floats of LDS one pixel's / filter row's K chunk takes (bf16: BK / 2, f32x3: three bf16 planes)
+  static constexpr int KF = BK * 4 / EPS;     // floats of LDS one pixel's / filter row's K chunk takes (bf16: BK / 2)
   static constexpr int GPR = BK / EPS;         // 16-byte global loads per input pixel and chunk
   static constexpr int GPRB = KF / 4;          // 16-byte global loads (= LDS slots) per filter row and slice
   static constexpr int CK = KF + 4;            // padded LDS row: conflict-free ds_read_b128
@@ -269,15 +268,15 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // and fits 99-104 registers without spilling.
 __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC> G;
-  constexpr bool BF16 = G::BF16, X3 = G::X3;
+  constexpr bool BF16 = G::BF16;
   constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored activation element
-  constexpr int WSZ = (BF16 || X3) ? 2 : 4;     // bytes per stored filter element
+  constexpr int WSZ = BF16 ? 2 : 4;     // bytes per stored filter element
   constexpr int EPS = G::EPS, GPR = G::GPR, GPRB = G::GPRB;
   constexpr int EPB = 16 / WSZ;                 // filter elements per 16-byte slot
   static_assert(TB == 1 || ((TB == 3 || TB == 9) && KS == 3 && !UPS) || (TB == 4 && UPS) || (TB == 2 && KS == 1 && !UPS && STRIDE == 1),
                 "filter slices per barrier: one tap, one row of a 3x3 filter, all nine; phase convolutions: the four taps of a phase");
   constexpr int NT = G::NT;
-  static_assert(KW == 1 || (NF > 0 && (BK / ((BF16 || X3) ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
+  static_assert(KW == 1 || (NF > 0 && (BK / (BF16 ? 16 : 8)) % KW == 0), "in-workgroup split-K: 32-column path (conv or SPADE), K steps of a chunk divisible by KW");
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -349,12 +348,10 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
 
   const char* xn = reinterpret_cast<const char*>(p.x) + (size_t)n * p.Hin * p.Win * p.xC * ESZ;
   const char* wb = reinterpret_cast<const char*>(p.w) + (p.w_mod ? (size_t)(n % p.w_mod) * p.w_stride * WSZ : 0);
-  const int wrow = G::TAPS * p.Cin;   // elements per filter row (f32x3: per plane)
-  // byte offset of the 16-byte slot g of filter row `row`, slice `tap`, chunk kc.  fp32 / bf16: [row][tap][Cin];
-  // f32x3: [row][tap][plane][Cin] bf16, slot g = plane * (BK / 8) + group
+  const int wrow = G::TAPS * p.Cin;   // elements per filter row
+  // byte offset of the 16-byte slot g of filter row `row`, slice `tap`, chunk kc: [row][tap][Cin]
   auto w_off = [&](int row, int tap, int kc, int g) -> size_t {
-    if constexpr (X3) return (((size_t)row * G::TAPS * 3 + tap * 3 + g / (BK / 8)) * p.Cin + kc + (g % (BK / 8)) * 8) * 2;
-    else return ((size_t)row * wrow + tap * p.Cin + kc + g * EPB) * WSZ;
+    return ((size_t)row * wrow + tap * p.Cin + kc + g * EPB) * WSZ;
   };
 
   // ---- operand staging, software-pipelined through registers: the global loads of the NEXT
@@ -480,25 +477,6 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
       int lpix = pix;
       if constexpr (STRIDE == 2) { const int ly = pix / G::IW, lx = pix % G::IW; lpix = ly * G::IWP + (lx & 1) * G::IWH + (lx >> 1); }
-      if constexpr (X3) {
-        // three bf16 planes per pixel row: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (the subtractions are exact)
-        const float e[4] = {v.x, v.y, v.z, v.w};
-        uint32_t hi[4], mi[4], lo[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint16_t hb = f32_to_bf16(e[k]);
-          const float r1 = e[k] - bf16_to_f32(hb);
-          const uint16_t mb = f32_to_bf16(r1);
-          const float r2 = r1 - bf16_to_f32(mb);
-          hi[k] = hb; mi[k] = mb; lo[k] = f32_to_bf16(r2);
-        }
-        if (tid + i * NT < total4) {
-          float* dst = sA + lpix * G::CK + ac4 * 2;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-          *reinterpret_cast<uint2*>(dst + BK / 2) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
-          *reinterpret_cast<uint2*>(dst + BK) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
-        }
-      } else
       if (tid + i * NT < total4) *reinterpret_cast<float4*>(sA + lpix * G::CK + ac4 * 4) = v;
     }
   };
@@ -571,37 +549,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       aoff[mf] = (r * G::IWP + c) * G::CK;
     }
     const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
-    static_assert(!(BF16 || X3) || (BK % 16 == 0 && NF > 0), "bf16 matrix-core paths: 16-channel steps, 32-column fragments");
-    if constexpr (X3) {
-      constexpr int KBW16 = BK / 16 / KW;
-#pragma unroll
-      for (int kj = 0; kj < KBW16; ++kj) {
-        const int kb = kw * KBW16 + kj;
-        bf16x8 a[MF][3], b[NFE][3];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[mf][pl] = *reinterpret_cast<const bf16x8*>(sA + aoff[mf] + pl * (BK / 2) + kb * 8 + lh * 4);
-#pragma unroll
-        for (int nf = 0; nf < NFE; ++nf)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b[nf][pl] = *reinterpret_cast<const bf16x8*>(sBrow + nf * 32 * G::CK + pl * (BK / 2) + kb * 8 + lh * 4);
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-          for (int nf = 0; nf < NFE; ++nf) {
-            f32x16& d = acc[ph * MF + mf][nf];
-            // small terms first, the hi*hi term last
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][2], b[nf][0], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][2], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][1], b[nf][1], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][1], b[nf][0], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][1], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf][0], b[nf][0], d, 0, 0, 0);
-          }
-      }
-      return;
-    }
+    static_assert(!BF16 || (BK % 16 == 0 && NF > 0), "bf16 matrix-core path: 16-channel steps, 32-column fragments");
     if constexpr (BF16) {
       {
         // v_mfma_f32_32x32x16_bf16: lane (row/col = l&31, half h = l>>5) holds k = 8h .. 8h+7 of a
@@ -861,9 +809,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         const int row = idx / GPRB, c4 = idx % GPRB;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad) {
-          size_t off;      // w2 [CoutPad][Cin2] (f32x3: [CoutPad][plane][Cin2] bf16)
-          if constexpr (X3) off = (((size_t)(n0 + row) * 3 + c4 / (BK / 8)) * p.Cin2 + kc + (c4 % (BK / 8)) * 8) * 2;
-          else off = ((size_t)(n0 + row) * p.Cin2 + kc + c4 * EPB) * WSZ;
+          const size_t off = ((size_t)(n0 + row) * p.Cin2 + kc + c4 * EPB) * WSZ;      // w2 [CoutPad][Cin2]
           v = *reinterpret_cast<const float4*>(w2b + off);
         }
         breg[i] = v;

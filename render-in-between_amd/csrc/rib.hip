@@ -38,7 +38,6 @@
 #define RIB_VSK(sec, ...) RIB_I_VSK(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VB(sec, ...) RIB_I_VB(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VBX(sec, ...) RIB_I_VBX(RIB_F_EXTERN, __VA_ARGS__)
-#define RIB_VX3(sec, ...) RIB_I_VX3(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_V1D(sec, ...) RIB_I_V1D(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VS1D(sec, ...) RIB_I_VS1D(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
@@ -52,7 +51,6 @@
 #undef RIB_VSK
 #undef RIB_VB
 #undef RIB_VBX
-#undef RIB_VX3
 #undef RIB_V1D
 #undef RIB_VS1D
 
@@ -204,7 +202,7 @@ typedef void (*IgemmFn)(const IgemmParams);
 struct Variant {
   int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
   IgemmFn fn;          // generic instantiation (fused-shortcut loop and input prologue compiled in)
-  int BF16 = 0;        // precision of this instantiation: PREC_F32 / PREC_BF16 (bf16 storage) / PREC_F32X3 (fp32 storage, split-bf16 operands)
+  int BF16 = 0;        // precision of this instantiation: PREC_F32 / PREC_BF16 (bf16 storage)
   IgemmFn fn_pro = nullptr;    // without the fused-shortcut loop
   IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int KW = 1;                  // in-workgroup split-K: KW groups of 4 waves (256*KW threads) per tile
@@ -215,7 +213,7 @@ struct Variant {
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
-    const int ck = (BF16 == PREC_BF16 ? BK / 2 : (BF16 == PREC_F32X3 ? 3 * BK / 2 : BK)) + 4;   // IgemmGeom::CK
+    const int ck = (BF16 == PREC_BF16 ? BK / 2 : BK) + 4;   // IgemmGeom::CK
     const bool db1 = KS == 1 && TB == 2;                                                        // 1x1, everything double-buffered
     const int main_loop = (((TB == 9 || db1) ? 2 : 1) * ih * iwp * ck + 2 * (db1 ? 1 : TB) * BN() * ck) * 4;   // IgemmGeom::NA, TBB
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
@@ -276,9 +274,6 @@ struct Variant {
           &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, false, KW, 2>, KW, 2},
 #define RIB_VS1D(sec, FRW, WM, WN, MF, NF, BK, KW) \
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, true, true, KW, 2>, 0, nullptr, nullptr, KW, 2},
-#define RIB_VX3(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
-  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 2, nullptr, nullptr, KW, TB},
 #define RIB_VBX(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, true, nullptr, nullptr, KW, TB},
@@ -337,7 +332,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ups ? 16 : ks * ks;
       const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0
-                                        : (v.BF16 == PREC_BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (v.BF16 == PREC_F32X3 ? (BK / 16) * v.MF * v.NF * 6 * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0));
+                                        : (v.BF16 == PREC_BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
       // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
@@ -369,19 +364,14 @@ struct PRef {
   size_t off = 0;   // bytes for WS, floats for WEIGHT, slot id for USER
 };
 
-// Streams of a plan: the SPADE condition encoder (ref_embedding) and the label branch of the mask
-// network do not depend on the main generator chain, so they run on side streams forked from the
-// caller's stream and joined by events where their results are consumed.  Several of the deep
-// layers fill well under half of the 256 CUs at batch 1: co-running branches fill the rest.
-enum { ST_MAIN = 0, ST_EMBED = 1, ST_LABEL = 2, ST_COUNT = 3 };
+// A plan runs its launches in order on the caller's stream.  (Rounds 1-2 carried an option to run the condition encoder
+// and the label branch on side streams: measured slower three times - two queues cost more than the overlap returns on
+// this runtime - and incompatible with the lifetime-shared workspace; retired in round 3.)
 
 struct Op {
   OpKind kind;
   int kclass;
   std::string name;
-  int stream = ST_MAIN;
-  std::vector<int> wait_ev;   // plan events this op waits for (on its stream) before it launches
-  int record_ev = -1;         // plan event recorded on its stream after it launches
   // igemm
   const Variant* var = nullptr;
   std::string for_op;        // a finalize launch emitted on behalf of this consumer (rib_time_op times them together)
@@ -450,7 +440,6 @@ struct Plan {
   bool labels_only = false;
   LabelSlots ls;
   int B, H, W;
-  int num_events = 0;
   size_t ws_bytes = 0;
   size_t ws_virtual = 0;   // bytes before lifetime-based reuse (one range per buffer)
   std::vector<Op> ops;
@@ -474,25 +463,20 @@ struct rib_handle {
   size_t d_blob_floats = 0;      // allocated size (the bf16 storage mode carries bf16 filter copies: a larger blob)
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
+  uint64_t layout_hash = 0;       // of the blob's offsets (assign_weight_layout); part of the blob header
   bool weights_ready = false;
   bool compute_bf16 = false;   // rib_set_compute_dtype: bf16 storage + bf16 matrix cores
-  bool compute_x3 = false;     //                         fp32 storage, split-bf16 (hi + mid + lo) matrix-core operands
-  int prec() const { return compute_bf16 ? PREC_BF16 : (compute_x3 ? PREC_F32X3 : PREC_F32); }
-  bool mc16() const { return compute_bf16 || compute_x3; }               // the matrix-core kernels read bf16 filter copies, 16-channel steps
+  int prec() const { return compute_bf16 ? PREC_BF16 : PREC_F32; }
+  bool mc16() const { return compute_bf16; }                             // the matrix-core kernels read bf16 filter copies, 16-channel steps
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
   int esz() const { return compute_bf16 ? 2 : 4; }                       // bytes per stored activation element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
-  // side streams (forked from / joined to the caller's stream with events) and the event pool
-  hipStream_t side[ST_COUNT] = {nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> events;
-  std::vector<hipStream_t> stream_pool;
-  bool use_streams = false;
   // profiling
   bool profiling = false;
-  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  std::vector<std::pair<int, hipEvent_t>> prof_events;   // (class of the launch behind the event, -1: end of a plan run)
   int64_t prof_launches[RIB_KC_COUNT] = {0};
   double prof_ms[RIB_KC_COUNT] = {0};
 };
@@ -540,8 +524,14 @@ static void launch_lowc(int ce, int ncol, bool bf16, int tw, dim3 grid, hipStrea
   else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(bf16, tw, grid, st, p);
 }
 
+// The blob starts with a header the importer checks (rib_import_weights): a blob is only meaningful to a handle with
+// the same precision mode and the same layout (which also depends on RIB_NO_WINO / RIB_NO_LOWC / RIB_NO_SPADE16 as read
+// when the layout was assigned).  64 floats are reserved; 8 words are used.
+enum { BLOB_HEADER_FLOATS = 64, BLOB_MAGIC = 0x57424952 /* "RIBW" */, BLOB_VERSION = 3 };
+struct BlobHeader { uint32_t magic, version, prec, reserved; uint64_t floats, layout_hash; };
+
 void assign_weight_layout(rib_handle* h) {
-  size_t off = 0;
+  size_t off = BLOB_HEADER_FLOATS;
   h->spades.clear(); h->spade_index.clear();
   auto take = [&](size_t nfloats) { size_t o = off; off += (nfloats + 63) / 64 * 64; return o; };
   for (auto& c : h->convs) {
@@ -605,8 +595,8 @@ void assign_weight_layout(rib_handle* h) {
     c.lowc_ce = ce; c.lowc_ncol = ncol;
     c.wl_off = take((size_t)9 * ce * ncol);
   }
-  if (h->mc16()) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float); f32x3: three planes
-    const size_t pl = h->compute_x3 ? 3 : 1;
+  if (h->mc16()) {   // bf16 copies of every filter tensor the matrix-core kernels read (two elements per float)
+    const size_t pl = 1;
     for (auto& c : h->convs) {
       if (!c.used) continue;
       c.w16_off = take((pl * c.coutp * c.ks * c.ks * c.cinp + 1) / 2);
@@ -615,6 +605,21 @@ void assign_weight_layout(rib_handle* h) {
     for (auto& sg : h->spades) sg.w16_off = take((pl * sg.npad * h->padc(sg.cond) + 1) / 2);
   }
   h->blob_floats = off;
+  // FNV-1a over every offset the kernels will be handed
+  uint64_t hs = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { hs ^= (v >> (8 * i)) & 0xff; hs *= 1099511628211ull; } };
+  for (const auto& c : h->convs)
+    for (uint64_t v : {(uint64_t)c.w_off, (uint64_t)c.b_off, (uint64_t)c.g_off, (uint64_t)c.be_off, (uint64_t)c.fb_off, (uint64_t)c.wp_off, (uint64_t)c.w16_off,
+                       (uint64_t)c.wp16_off, (uint64_t)c.wu_off, (uint64_t)c.wu4_off, (uint64_t)c.zero_off, (uint64_t)c.wl_off}) mix(v);
+  for (const auto& sg : h->spades)
+    for (uint64_t v : {(uint64_t)sg.w_off, (uint64_t)sg.b_off, (uint64_t)sg.w16_off, (uint64_t)sg.w1_off, (uint64_t)sg.b1_off}) mix(v);
+  mix(off);
+  h->layout_hash = hs;
+}
+BlobHeader blob_header_of(const rib_handle* h) {
+  BlobHeader bh; bh.magic = BLOB_MAGIC; bh.version = BLOB_VERSION; bh.prec = (uint32_t)h->prec(); bh.reserved = 0;
+  bh.floats = h->blob_floats; bh.layout_hash = h->layout_hash;
+  return bh;
 }
 
 void register_tensors(rib_handle* h) {
@@ -667,10 +672,6 @@ struct Builder {
   int B;
   size_t ws = 0;
   std::string error;
-  int cur_stream = ST_MAIN;
-  std::vector<int> pending_waits;   // attached to the next op pushed
-
-  int new_event() { return P->num_events++; }
   bool mark_label = false;
   bool defer_stats = true;   // false: every k_stats_finalize launch is emitted where its producer is (labels-only plans)
   // a consumer needs the (scale, shift) ARRAYS of n: emit the finalize launch now if it is still pending
@@ -693,14 +694,8 @@ struct Builder {
   int TB_() const { return tuneB > 0 ? tuneB : B; }
   void push(Op op) {
     op.label_only = mark_label;
-    op.stream = cur_stream;
-    op.wait_ev.insert(op.wait_ev.end(), pending_waits.begin(), pending_waits.end());
-    pending_waits.clear();
     P->ops.push_back(op);
   }
-  // record an event after the last op pushed
-  int record_after_last() { if (P->ops.empty()) return -1; const int e = new_event(); P->ops.back().record_ev = e; return e; }   // -1: nothing to wait for
-  void wait_before_next(int ev) { if (ev >= 0) pending_waits.push_back(ev); }
 
   // Workspace layout.  During the build every buffer gets its own range of a virtual address space (bump
   // allocation, as the plan used to run: 1.1 GB at 512x512); assign_physical() then gives buffers whose lifetimes
@@ -730,10 +725,8 @@ struct Builder {
     a.usrc[0] = s0; a.uc[0] = c0; a.usrc[1] = s1; a.uc[1] = c1; a.usrc[2] = s2; a.uc[2] = c2;
     return a;
   }
-  // every consumer of a packed input tensor has a k_conv_lowc instantiation (and the plan is single-stream: the side-stream
-  // experiment forks at the pack launches)
+  // every consumer of a packed input tensor has a k_conv_lowc instantiation
   bool lowc_serves(std::initializer_list<const char*> names) {
-    if (h->use_streams || getenv("RIB_LBL_AT")) return false;
     for (const char* nm : names) {
       auto it = h->conv_index.find(nm);
       if (it == h->conv_index.end() || !h->convs[it->second].wl_off) return false;
@@ -881,7 +874,7 @@ struct Builder {
       // split-K: the conv writes raw partial slabs; a second kernel sums them and runs the epilogue
       const size_t slab_off = alloc((size_t)S * B * Hout * Wout * c.coutp * sizeof(float));
       op.slab = WS(slab_off);
-      Op e; e.kind = OP_SPLITEPI; e.kclass = RIB_KC_ELTWISE; e.name = opname + ".splitk_sum";
+      Op e; e.kind = OP_SPLITEPI; e.kclass = RIB_KC_CONVAUX; e.name = opname + ".splitk_sum";
       memset(&e.sp, 0, sizeof e.sp);
       e.sp.ksplit = S; e.sp.B = B; e.sp.CoutPad = c.coutp; e.sp.yC = p.yC; e.sp.yoff = p.yoff; e.sp.Cout = p.Cout;
       e.sp.act = p.act; e.sp.resC = p.resC; e.sp.res_ups = p.res_ups; e.sp.Hout = Hout; e.sp.Wout = Wout;
@@ -972,7 +965,7 @@ struct Builder {
     const size_t v_off = alloc((size_t)B * NP * ntiles * c.cinp * sizeof(float));
     const size_t m_off = alloc((size_t)B * NP * ntiles * c.coutp * sizeof(float));
     {   // input transform (with the convolution's prologue)
-      Op op; op.kind = OP_WINO_IN; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_in"; op.for_op = gname; op.wino_m = wm;
+      Op op; op.kind = OP_WINO_IN; op.kclass = RIB_KC_CONVAUX; op.name = opname + ".wino_in"; op.for_op = gname; op.wino_m = wm;
       memset(&op.wi, 0, sizeof op.wi);
       op.wi.H = a.in.H; op.wi.W = a.in.W; op.wi.xC = a.in.Cp; op.wi.Cin = c.cinp; op.wi.tilesY = tilesY; op.wi.tilesX = tilesX;
       op.wi.pro_lrelu = a.pro_lrelu ? 1 : 0;
@@ -1012,7 +1005,7 @@ struct Builder {
       push(op);
     }
     {   // output transform + the convolution's epilogue
-      Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_ELTWISE; op.name = opname + ".wino_out"; op.for_op = gname; op.wino_m = wm;
+      Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_CONVAUX; op.name = opname + ".wino_out"; op.for_op = gname; op.wino_m = wm;
       memset(&op.wo, 0, sizeof op.wo);
       // thread = (tile, output row, 4 channels): F(2x2) 128 / (coutp/4) tiles per block, F(4x4) 256 / (coutp/4) (tile, row) units
       const int slots = 128 / (c.coutp / 4);
@@ -1191,7 +1184,9 @@ struct Builder {
       Norm no = lastl ? ncat : norm(h->padc(cd.cout));
       ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
       if (have) { a.pro = &ncur; a.pro_lrelu = true; }
-      if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; }
+      // the last level's (scale, shift) land in the shared arrays of the concatenated tensor: its finalize is emitted at
+      // the producer (`no` is a local copy of ncat: a deferred finalize attached to it would be lost)
+      if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; a.stats_now = true; }
       a.want_stats = true; a.stats_out = &no; a.affine = true;
       if (!conv(a, cd.name)) return false;
       if (!lastl) tap(std::string("mask.") + (b == 0 ? "lbl_" : "img_") + std::to_string(i) + ".raw", o);
@@ -1221,7 +1216,7 @@ struct Builder {
   // the plan (the label-only results rib_chain gathers into their slots before it runs the frame) are live from the
   // start, tapped activations (debug) until the end.
   bool assign_physical() {
-    const bool reuse = !getenv("RIB_NO_WS_REUSE") && !h->use_streams && !P->labels_only;
+    const bool reuse = !getenv("RIB_NO_WS_REUSE") && !P->labels_only;
     if (!reuse) { P->ws_bytes = ws; return true; }
     bool bad = false;
     for (size_t i = 0; i < P->ops.size(); ++i)
@@ -1334,50 +1329,36 @@ struct Builder {
     mark_label = true;
     if (!vL) pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
     mark_label = false;
-    const int ev_label = record_after_last();   // also the fork point of the side streams
     if (!vI) pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
-    // RIB_LBL_AT=<i>: (experiment) only the label branch goes to a side stream, forked when the main
-    // chain reaches down_<i>, i.e. next to the small-map layers that cannot fill the chip
-    const int lbl_at = getenv("RIB_LBL_AT") ? atoi(getenv("RIB_LBL_AT")) : -1;
-    if (lbl_at < 0) { cur_stream = ST_EMBED; wait_before_next(ev_label); }
     if (!vE) pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
 
     // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
     std::vector<Act> cond(c.emb_down + 1);
-    std::vector<int> ev_cond(c.emb_down + 1, -1);
     {
       const ConvDef& cf = conv_of(h, "ref_embedding.conv_first");
       cond[0] = act(cf.cout, H, W);
       ConvArgs a; a.cd = &cf; a.in = Ein; a.out = cond[0]; a.act = ACT_LRELU;
       if (!conv(a, "ref_embedding.conv_first")) return false;
-      ev_cond[0] = record_after_last();
       tap("cond_0", cond[0]);
       for (int i = 0; i < c.emb_down; ++i) {
         const ConvDef& cd = conv_of(h, "ref_embedding.down_" + std::to_string(i));
         cond[i + 1] = act(cd.cout, cond[i].H / 2, cond[i].W / 2);
         ConvArgs b; b.cd = &cd; b.in = cond[i]; b.out = cond[i + 1]; b.act = ACT_LRELU;
         if (!conv(b, cd.name)) return false;
-        ev_cond[i + 1] = record_after_last();
         tap("cond_" + std::to_string(i + 1), cond[i + 1]);
       }
     }
 
-    // ---- label branch of the mask network (depends only on the label map): side stream ----
+    // ---- label branch of the mask network (depends only on the label map) ----
     const std::string m = "flow_network_temp";
     const int chm = g.mask_nf(c.mask_down);
     const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
     if (h->padc(chm) != chm) { error = "mask network width must be a multiple of 8 (16 with bf16 storage)"; return false; }
     Act CAT = act(2 * chm, Hm, Wm);
     Norm ncat = norm(CAT.Cp);
-    int ev_lbl = -1;
-    if (lbl_at < 0) {
-      cur_stream = ST_LABEL; wait_before_next(ev_label);
-      mark_label = true;
-      if (!mask_branch(0, L, CAT, ncat, chm)) return false;
-      mark_label = false;
-      ev_lbl = record_after_last();
-    }
-    cur_stream = ST_MAIN;
+    mark_label = true;
+    if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+    mark_label = false;
 
     // ---- main generator (generator.py:201-228) ----
     Act x; Norm nx;
@@ -1394,16 +1375,6 @@ struct Builder {
     for (int i = 0; i <= D; ++i) {
       Act out; Norm nout;
       const bool last = (i == D);
-      if (i == std::min(lbl_at, D) && lbl_at >= 0) {
-        const int ev_fork = record_after_last();
-        cur_stream = ST_LABEL; wait_before_next(ev_fork);
-        mark_label = true;
-        if (!mask_branch(0, L, CAT, ncat, chm)) return false;
-        mark_label = false;
-        ev_lbl = record_after_last();
-        cur_stream = ST_MAIN;
-      }
-      if (lbl_at < 0) wait_before_next(ev_cond[std::min(c.emb_down, i)]);
       if (!spade_block("down_" + std::to_string(i), x, false, nx, cond[std::min(c.emb_down, i)], &out, last ? &nout : nullptr)) return false;
       if (!last) {   // self.downsample = AvgPool2d(3, 2, 1) (generator.py:127,207-208)
         if (out.Cp % 4 != 0 || 256 % (out.Cp / 4) != 0) { error = "avgpool: unsupported channel count"; return false; }
@@ -1452,7 +1423,6 @@ struct Builder {
 
     // ---- MaskGenerator (generator.py:493-510): image branch, then join with the label branch ----
     if (!mask_branch(1, I9, CAT, ncat, chm)) return false;
-    wait_before_next(ev_lbl);
     tap("mask.cat.raw", CAT);
     Act r; bool first = true;
     for (int i = 0; i < c.mask_res_blocks; ++i) {
@@ -1564,25 +1534,15 @@ void launch_head(int co, int cin, bool bf16, dim3 grid, hipStream_t st, const Ig
   else { if (co == 1) launch_head_t<1, 32>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 32>(bf16, grid, st, p); else launch_head_t<3, 32>(bf16, grid, st, p); }
 }
 
-int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool single_stream = false, bool skip_label_ops = false) {
-  const bool multi = h->use_streams && !single_stream && h->side[ST_EMBED] != nullptr;
-  if (multi)
-    while ((int)h->events.size() < P->num_events) {
-      hipEvent_t e;
-      HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      h->events.push_back(e);
-    }
+int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool skip_label_ops = false) {
   const bool bf16 = h->compute_bf16;
   for (Op& op : P->ops) {
     if (skip_label_ops && op.label_only) continue;     // done for the whole chain by the labels-only plan
-    // in single-stream mode the plan order is already a valid topological order
-    hipStream_t st = (multi && op.stream != ST_MAIN) ? h->side[op.stream] : caller;
-    if (multi)
-      for (int ev : op.wait_ev) HIP_TRY(h, hipStreamWaitEvent(st, h->events[ev], 0));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling) {
-      HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+    if (h->profiling) {      // one event in front of every launch (rib.h: a launch is charged the time to the next event)
+      hipEvent_t e0 = nullptr;
+      HIP_TRY(h, hipEventCreate(&e0));
       HIP_TRY(h, hipEventRecord(e0, st));
+      h->prof_events.push_back({op.kclass, e0});
     }
     switch (op.kind) {
       case OP_IGEMM: {
@@ -1681,11 +1641,12 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t caller, bool
         else hipLaunchKernelGGL(k_pack<false>, op.grid, dim3(256), 0, st, p);
       } break;
     }
-    if (h->profiling) {
-      HIP_TRY(h, hipEventRecord(e1, st));
-      h->prof_events.push_back({op.kclass, {e0, e1}});
-    }
-    if (multi && op.record_ev >= 0) HIP_TRY(h, hipEventRecord(h->events[op.record_ev], st));
+  }
+  if (h->profiling) {        // closes the last launch's interval
+    hipEvent_t e1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e1, st));
+    h->prof_events.push_back({-1, e1});
   }
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
@@ -1733,19 +1694,6 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float));
     h->d_blob_floats = h->blob_floats;
-    // Side streams are opt-in (RIB_STREAMS="i,j" picks two of a small pool for the condition encoder
-    // and the label branch): HIP multiplexes streams onto a few hardware queues and a side stream
-    // that lands on the caller's queue only adds event traffic (stream_overlap_probe.py).
-    if (const char* sel = getenv("RIB_STREAMS")) {
-      int a = 1, b = 2;
-      sscanf(sel, "%d,%d", &a, &b);
-      for (int i = 0; i < 6 && e == hipSuccess; ++i) {
-        hipStream_t st;
-        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        h->stream_pool.push_back(st);
-      }
-      if (e == hipSuccess && a >= 0 && a < 6 && b >= 0 && b < 6) { h->side[ST_EMBED] = h->stream_pool[a]; h->side[ST_LABEL] = h->stream_pool[b]; h->use_streams = true; }
-    } else h->use_streams = false;
     if (e != hipSuccess) { g_create_error = fmt("rib_create: device %d: %s", device, hipGetErrorString(e)); return RIB_ERR_HIP; }
   }
   *out = h.release();
@@ -1755,9 +1703,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 void rib_destroy(rib_handle* h) {
   if (!h) return;
   if (h->d_blob) (void)hipFree(h->d_blob);
-  for (hipStream_t st : h->stream_pool) (void)hipStreamDestroy(st);
-  for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-  for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+  for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
   delete h;
 }
 
@@ -1797,6 +1743,7 @@ int rib_finalize_weights(rib_handle* h) {
   for (auto& t : h->tensors)
     if (!t.set) return fail(h, RIB_ERR_MISSING, fmt("missing key '%s' in state_dict (strict load)", t.name.c_str()));
   std::vector<float> blob(h->blob_floats, 0.f);
+  { const BlobHeader bh = blob_header_of(h); memcpy(blob.data(), &bh, sizeof bh); }
   for (auto& c : h->convs) {
     if (!c.used) continue;
     const std::string p = c.name + ".layers.conv";
@@ -1931,20 +1878,10 @@ int rib_finalize_weights(rib_handle* h) {
     }
   }
   if (h->mc16()) {
-    // rows of `rowlen` K-contiguous elements: bf16 -> [row][rowlen]; f32x3 -> [row][plane][rowlen] with
-    // hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (exact subtractions), as the kernels split activations
-    const bool x3 = h->compute_x3;
-    auto bf = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    // rows of `rowlen` K-contiguous elements: [row][rowlen] bf16
     auto to16 = [&](size_t src, size_t dst, size_t rows, size_t rowlen) {
       uint16_t* d = reinterpret_cast<uint16_t*>(&blob[dst]);
-      for (size_t r = 0; r < rows; ++r)
-        for (size_t i = 0; i < rowlen; ++i) {
-          const float w = blob[src + r * rowlen + i];
-          if (!x3) { d[r * rowlen + i] = host_bf16(w); continue; }
-          const uint16_t hb = host_bf16(w); const float r1 = w - bf(hb);
-          const uint16_t mb = host_bf16(r1); const float r2 = r1 - bf(mb);
-          d[(r * 3 + 0) * rowlen + i] = hb; d[(r * 3 + 1) * rowlen + i] = mb; d[(r * 3 + 2) * rowlen + i] = host_bf16(r2);
-        }
+      for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_bf16(blob[src + i]);
     };
     for (auto& c : h->convs) {
       if (!c.used) continue;
@@ -1987,6 +1924,18 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
   if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
   if (h->device < 0) return fail(h, RIB_ERR_INVALID, "rib_import_weights: host-only handle");
   HIP_TRY(h, hipSetDevice(h->device));
+  {   // the byte count alone does not identify a layout: check the header (a 32-byte read behind whatever filled src on this stream)
+    BlobHeader got;
+    HIP_TRY(h, hipMemcpyAsync(&got, src, sizeof got, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+    const BlobHeader want = blob_header_of(h);
+    if (got.magic != want.magic || got.version != want.version)
+      return fail(h, RIB_ERR_INVALID, "rib_import_weights: not a weight blob of this library version (bad header)");
+    if (got.prec != want.prec || got.floats != want.floats || got.layout_hash != want.layout_hash)
+      return fail(h, RIB_ERR_INVALID, fmt("rib_import_weights: blob was exported by a handle with another precision mode or filter layout "
+                                          "(mode %u vs %u, layout hash %016llx vs %016llx)", got.prec, want.prec,
+                                          (unsigned long long)got.layout_hash, (unsigned long long)want.layout_hash));
+  }
   if (h->d_blob_floats != h->blob_floats) {
     if (h->d_blob) (void)hipFree(h->d_blob);
     h->d_blob = nullptr; h->d_blob_floats = 0;
@@ -1999,15 +1948,15 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
 }
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
-  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16 && dtype != RIB_DTYPE_F32X3)) return RIB_ERR_INVALID;
-  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16) && h->compute_x3 == (dtype == RIB_DTYPE_F32X3)) return RIB_OK;
+  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
+  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16)) return RIB_OK;
   // The storage type decides the activation / filter layout (bf16: 16-channel minimum, bf16 filter copies in the
   // blob): plans and the weight layout are rebuilt, and the folded blob has to be produced again - by
   // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
   // exported by a handle of the same storage type.
   h->plans.clear();
+  h->choices.clear();      // tuned variant indices belong to the previous precision's kernels: back to the cost model until re-pinned
   h->compute_bf16 = dtype == RIB_DTYPE_BF16;
-  h->compute_x3 = dtype == RIB_DTYPE_F32X3;
   assign_weight_layout(h);
   const bool had = h->weights_ready || !h->host_blob.empty();
   h->weights_ready = false;
@@ -2164,7 +2113,7 @@ namespace {
 // label-only work is batched over the chain when it has more than one frame, on one stream (RIB_NO_LABEL_BATCH=1 disables)
 bool chain_batches_labels(const rib_handle* h, int T, int B) {
   // T * B * split-K (<= 16) indexes blockIdx.z (< 65536) of the batched launches
-  return T > 1 && B < 128 && (long)T * B < 4096 && !h->use_streams && !getenv("RIB_NO_LABEL_BATCH");
+  return T > 1 && B < 128 && (long)T * B < 4096 && !getenv("RIB_NO_LABEL_BATCH");
 }
 }  // namespace
 
@@ -2207,7 +2156,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
       Resolver RL; RL.ws = lws; RL.blob = h->d_blob;
       for (int u = 0; u < U_COUNT; ++u) RL.user[u] = nullptr;
       RL.user[U_LABEL] = labels;
-      rc = run_plan(h, PL, RL, st, true);
+      rc = run_plan(h, PL, RL, st);
       if (rc) return rc;
     } else PL = nullptr;     // a caller that sized the workspace with rib_workspace_bytes: per-frame label work
   }
@@ -2234,7 +2183,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
     R.user[U_LABEL] = labels + (size_t)t * lframe; R.user[U_FAKE] = dains + (size_t)t * frame; R.user[U_PREV] = prev;
     R.user[U_IMG] = img_t; R.user[U_MASK] = mask_t;
     R.user[U_FUSE] = chain_fused ? fuse_t : nullptr;     // the mask head writes the blend itself when it can
-    rc = run_plan(h, P, R, st, false, PL != nullptr);
+    rc = run_plan(h, P, R, st, PL != nullptr);
     if (rc) return rc;
     if (!chain_fused) {
       rc = rib_blend(h, B, c.image_nc, H, W, img_t, mask_t, dains + (size_t)t * frame, fuse_t, hip_stream);
@@ -2359,7 +2308,7 @@ int rib_variant_info(int idx, int geom[12]) {
   const Variant& v = kVariants[idx];
   const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.TB};
   for (int i = 0; i < 12; ++i) geom[i] = g[i];
-  return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage, 2 f32x3
+  return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage
 }
 
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit) {
@@ -2400,11 +2349,11 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   R.user[U_FUSE] = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const bool was = h->profiling; h->profiling = false;
-  rc = run_plan(h, &sub, R, st, true);   // warm-up
+  rc = run_plan(h, &sub, R, st);   // warm-up
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
   HIP_TRY(h, hipEventRecord(e0, st));
-  for (int i = 0; i < iters && rc == RIB_OK; ++i) rc = run_plan(h, &sub, R, st, true);
+  for (int i = 0; i < iters && rc == RIB_OK; ++i) rc = run_plan(h, &sub, R, st);
   HIP_TRY(h, hipEventRecord(e1, st));
   HIP_TRY(h, hipEventSynchronize(e1));
   float ms = 0.f;
@@ -2417,7 +2366,7 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
 
 int rib_profile_begin(rib_handle* h) {
   if (!h) return RIB_ERR_INVALID;
-  for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+  for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
   h->prof_events.clear();
   h->profiling = true;
   return RIB_OK;
@@ -2427,13 +2376,15 @@ int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms
   if (!h || !launches || !ms) return RIB_ERR_INVALID;
   h->profiling = false;
   for (int i = 0; i < RIB_KC_COUNT; ++i) { launches[i] = 0; ms[i] = 0.0; }
-  for (auto& pe : h->prof_events) {
-    HIP_TRY(h, hipEventSynchronize(pe.second.second));
+  if (!h->prof_events.empty()) HIP_TRY(h, hipEventSynchronize(h->prof_events.back().second));
+  for (size_t i = 0; i + 1 < h->prof_events.size(); ++i) {
+    const int kc = h->prof_events[i].first;
+    if (kc < 0) continue;                       // end marker of a plan run: the gap to the next run belongs to no launch
     float t = 0.f;
-    HIP_TRY(h, hipEventElapsedTime(&t, pe.second.first, pe.second.second));
-    launches[pe.first] += 1; ms[pe.first] += (double)t;
-    (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second);
+    HIP_TRY(h, hipEventElapsedTime(&t, h->prof_events[i].second, h->prof_events[i + 1].second));
+    launches[kc] += 1; ms[kc] += (double)t;
   }
+  for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
   h->prof_events.clear();
   return RIB_OK;
 }

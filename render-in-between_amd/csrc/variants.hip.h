@@ -45,9 +45,6 @@
 // bf16-storage variant with explicit wave groups / slices per barrier (one instantiation: shortcut loop where it can exist, prologue)
 #define RIB_I_VBX(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
   F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
-// f32x3 variant (fp32 storage, operands split into three bf16 terms): PREC = 2
-#define RIB_I_VX3(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
-  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
 // 1x1 with input tile and filter slice double-buffered (TB = 2: one barrier per chunk), optional wave groups; conv (generic = pro, lean) and SPADE
 #define RIB_I_V1D(F, FRW, WM, WN, MF, NF, BK, KW)                                \
   F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2)          \

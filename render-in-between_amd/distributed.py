@@ -26,10 +26,37 @@ def free_port() -> int:
 
 
 def launch_command(script: str, argv: Sequence[str], nproc: int, port: int = None) -> List[str]:
-    """The command that starts `nproc` ranks of `script` on this node, one per GPU, exactly as the driver does it
-    (python -m torch.distributed.run, rendezvous on 127.0.0.1)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
-            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script] + list(argv)
+    """The command that starts `nproc` ranks of `script` on this node, one per GPU (python -m torch.distributed.run,
+    rendezvous on 127.0.0.1).  With a port: exactly the driver's form (--master-addr / --master-port).  Without one:
+    --standalone, where the launcher's own TCP store binds a free port and keeps it - no window between picking a port
+    and binding it in which another process could take it."""
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc))]
+    if port is None:
+        rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
+    else:
+        rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(int(port))]
+    return head + rdzv + [script] + list(argv)
+
+
+def rank_device_index(environ=None) -> int:
+    """HIP device of this rank: LOCAL_RANK, one process per GPU (torch.distributed.run gives the N ranks of a node the
+    LOCAL_RANKs 0..N-1: N distinct devices).  RIB_BENCH_DEVICE overrides it - only to rehearse several ranks on a
+    one-GPU box."""
+    env = os.environ if environ is None else environ
+    return int(env.get("RIB_BENCH_DEVICE", env.get("LOCAL_RANK", "0")))
+
+
+def device_identity(index: int) -> str:
+    """'cuda:<i> <name> pci <bus id>' of a visible device, for the per-rank line of the multi-GPU bench."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bus = getattr(p, "pci_bus_id", None)
+        dom = getattr(p, "pci_domain_id", 0)
+        dev = getattr(p, "pci_device_id", 0)
+        where = "%04x:%02x:%02x" % (dom, bus, dev) if bus is not None else "?"
+        return "cuda:%d %s pci %s" % (index, p.name, where)
+    except Exception as e:                                          # noqa: BLE001  (identity is informational)
+        return "cuda:%d (%s)" % (index, type(e).__name__)
 
 
 def self_launch(script: str, argv: Sequence[str], nproc: int) -> int:
@@ -56,14 +83,35 @@ def gather_rows(row: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return buf
 
 
-def init_process_group(backend: str = None):
+def init_process_group(backend: str = None, device: torch.device = None):
+    """`device`: this rank's GPU.  Handed to init_process_group as device_id with the RCCL backend, so that the
+    communicator is bound to it up front (eager init, no guessing from the rank number at the first collective)."""
     if dist.is_initialized():
         return
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
-    dist.init_process_group(backend=backend)
+    kw = {}
+    if backend == "nccl" and device is not None and torch.device(device).type == "cuda":
+        kw["device_id"] = torch.device(device)
+    dist.init_process_group(backend=backend, **kw)
+
+
+def agree_or_raise(ok: bool, what: str, device=None):
+    """Every rank calls this with its own verdict; all ranks raise together when any of them failed (one
+    all-reduce(MIN) of a flag).  Used in front of a collective that only one rank prepares - rank 0 reading the
+    checkpoint before the weight broadcast - so that a failure there ends the job with ONE clear error instead of
+    leaving the other ranks blocked in the collective until the launcher tears them down."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not ok:
+            raise RuntimeError(what)
+        return
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise RuntimeError(what if not ok else "another rank failed: " + what)
 
 
 def shard_units(num_units: int, rank: int, world: int) -> List[int]:
@@ -80,8 +128,9 @@ def broadcast_blob(buf: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 def broadcast_weights(gen, src: int = 0) -> float:
     """Rank `src` holds loaded weights; every other rank receives the folded
-    device blob (one RCCL broadcast, ~123 MB fp32) and adopts it.  Returns the
-    broadcast wall time in ms (synchronised)."""
+    device blob (one RCCL broadcast: ~0.3 GB in fp32 mode with the Winograd-domain filter sets of the deep layers,
+    ~0.19 GB bf16) and adopts it (rib_import_weights checks the blob's header: mode and layout must match).
+    Returns the broadcast wall time in ms (synchronised)."""
     rank = dist.get_rank()
     if rank == src:
         buf = gen.export_weights()

@@ -34,12 +34,25 @@ def load_generator(config, device=None, rank=0, world=1, dtype="f32"):
     path = config.model_pretrain_G
     if not os.path.isfile(path):
         raise ValueError("=> No checkpoint found at '{}'".format(path))
+    err = None
     if rank == 0:
-        checkpoint = torch.load(path, map_location="cpu")
-        print("=> Loaded checkpoint '{}'".format(path))
-        net_G.load_state_dict(checkpoint)
+        try:
+            checkpoint = torch.load(path, map_location="cpu")
+            print("=> Loaded checkpoint '{}'".format(path))
+            net_G.load_state_dict(checkpoint)
+        except Exception as e:                  # noqa: BLE001  (re-raised below, on every rank)
+            if world == 1:
+                raise
+            err = e
     if world > 1:
         from render_in_between_amd import distributed as ribdist
+        # only rank 0 touched the file: the other ranks learn here whether the broadcast will happen at all
+        try:
+            ribdist.agree_or_raise(err is None, "rank 0 could not load '{}': {!r}".format(path, err), net_G.device)
+        except RuntimeError:
+            if err is not None:
+                raise err
+            raise
         ms = ribdist.broadcast_weights(net_G, src=0)
         if rank == 0:
             print("=> weights broadcast to {} ranks in {:.1f} ms".format(world, ms))
@@ -60,9 +73,9 @@ def main(opts):
     config.eval_dir = opts.save_dir
     device = None
     if world > 1:
-        device = torch.device("cuda", int(os.environ.get("RIB_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        device = torch.device("cuda", ribdist.rank_device_index())
         torch.cuda.set_device(device)
-        ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"))
+        ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"), device)
     net_G = load_generator(config, device, rank, world, opts.dtype)
     evaluator = Evaluator(config)
     train_dir = os.path.join(opts.input_dir, "inputs")
@@ -82,7 +95,7 @@ if __name__ == "__main__":
     parser.add_argument("--save-dir", type=str, default="../example", help="outputs path")
     parser.add_argument("--input-dir", type=str, required=True, help="input low FPS frames and pose input")
     parser.add_argument("--seed", type=int, default=123)
-    parser.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32",
+    parser.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                         help="f32: the reference's arithmetic (default); bf16: bf16 storage, ~2x the frame rate, ~1e-2 mean deviation "
                              "(not in the reference: it is fp32 only)")
     parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")

@@ -20,6 +20,8 @@ residual: OpenCV's SIMD builds evaluate the vertical pass in float32 (`VResizeCu
 fixed-point definition restated here by one grey level on isolated pixels.  `oracle/resize_ref.py` is the slow scalar
 statement of the same definition (written independently, pixel by pixel) that the tests hold this version to.
 """
+import functools
+
 import numpy as np
 
 _COEF_BITS = 11
@@ -47,8 +49,11 @@ def _cubic_taps(dst, src):
     return idx, coef
 
 
+@functools.lru_cache(maxsize=32)
 def _tap_matrix(dst, src):
-    """The taps of one axis as a CSR matrix [dst, src] (clamped taps that coincide add up, as in HResizeCubic)."""
+    """The taps of one axis as a CSR matrix [dst, src] (clamped taps that coincide add up, as in HResizeCubic).
+    Cached per (dst, src): a clip resizes every frame between the same two sizes, on several decode threads (the
+    matrix is only read afterwards).  scipy is a dependency of the folder driver (declared in README)."""
     from scipy import sparse
     idx, coef = _cubic_taps(dst, src)
     rows = np.repeat(np.arange(dst), 4)

@@ -148,6 +148,10 @@ def test_self_launch_command_and_rank_detection(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
     assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--mode", "clips"]
+    # without a port the launcher's own store binds a free one (no pick-then-bind window), still on 127.0.0.1
+    cmd = ribdist.launch_command("/x/bench.py", ["--gpus", "8", "--mode", "clips"], 8)
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--mode", "clips"]
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("RANK", raising=False)
     assert not ribdist.is_rank_process()
@@ -178,3 +182,53 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
     assert e.value.code == 0 and calls == [(os.path.join(root, "bench.py"), ["--gpus", "4", "--mode", "clips", "--steps", "2"], 4)]
     a = bench.parse_args(["--gpus", "8", "--mode", "clips"])
     assert a.frames == 32 and a.size == 512 and a.batch == 1 and a.cpu_frames >= 5
+
+
+def test_eight_ranks_map_to_eight_devices(monkeypatch):
+    """`bench.py --gpus 8 --mode clips`: the parent builds ONE torch.distributed.run command for 8 ranks, and the
+    ranks it starts (LOCAL_RANK 0..7) pick 8 different HIP devices; RIB_BENCH_DEVICE is the one-GPU rehearsal switch."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = []
+    monkeypatch.setattr("subprocess.call", lambda cmd, env=None: seen.append((cmd, env)) or 0)
+    assert ribdist.self_launch(os.path.join(root, "bench.py"), ["--gpus", "8", "--mode", "clips"], 8) == 0
+    (cmd, env), = seen
+    assert cmd[:3] == [__import__("sys").executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "8", "--mode", "clips"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    devs = [ribdist.rank_device_index({"LOCAL_RANK": str(r), "RANK": str(r), "WORLD_SIZE": "8"}) for r in range(8)]
+    assert devs == list(range(8))
+    assert ribdist.rank_device_index({"LOCAL_RANK": "5", "RIB_BENCH_DEVICE": "0"}) == 0
+    assert ribdist.rank_device_index({}) == 0
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ribdist.init_process_group("gloo")
+    out = []
+    ribdist.agree_or_raise(True, "fine")                       # everybody fine: returns on every rank
+    try:
+        ribdist.agree_or_raise(rank != 0, "rank 0 could not load the checkpoint")   # rank 0 failed: EVERY rank raises
+        out.append("no error")
+    except RuntimeError as e:
+        out.append(str(e))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_rank0_ends_every_rank_before_the_broadcast():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == ["rank 0 could not load the checkpoint"]
+    assert res[1] == ["another rank failed: rank 0 could not load the checkpoint"]

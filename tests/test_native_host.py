@@ -144,8 +144,7 @@ def test_partial_reload_after_finalize_folds_old_and_new_tensors(lib):
 
 
 def test_precision_mode_switch_refolds_the_weights(lib):
-    """rib_set_compute_dtype changes the blob layout (bf16: 16-channel minimum, bf16 filter copies; f32x3: three-plane
-    copies).  A handle that still holds the state-dict tensors re-folds by itself; the fp32 section still undoes to the
+    """rib_set_compute_dtype changes the blob layout (bf16: 16-channel minimum, bf16 filter copies).  A handle that still holds the state-dict tensors re-folds by itself; the fp32 section still undoes to the
     oracle's fold; plans of every mode build at odd sizes; an unknown mode is refused."""
     cfg = rib.hsm_gen_config(**MID_CFG)
     spec, h = host_handle(lib, cfg)
@@ -157,7 +156,7 @@ def test_precision_mode_switch_refolds_the_weights(lib):
     assert lib.rib_finalize_weights(h) == 0
     n32 = lib.rib_weights_bytes(h)
     sizes = {}
-    for mode in (1, 2, 0):
+    for mode in (1, 0):
         assert lib.rib_set_compute_dtype(h, mode) == 0, lib.rib_last_error(h)
         sizes[mode] = lib.rib_weights_bytes(h)
         for cname in ("ref_embedding.conv_first", "down_1.conv_block_0", "conv_img"):
@@ -167,15 +166,15 @@ def test_precision_mode_switch_refolds_the_weights(lib):
             assert np.abs(w - w_ref.numpy()).max() <= 2e-6 * float(w_ref.abs().max()), (mode, cname)
         for (B, H, W) in ((1, 64, 64), (2, 48, 80), (1, 16, 16)):
             assert lib.rib_workspace_bytes(h, B, H, W) > 0, (mode, lib.rib_last_error(h))
-    # (fp32 carries the Winograd-domain filters of the deep 3x3 layers; bf16 / f32x3 carry bf16 / three-plane copies instead)
-    assert sizes[0] == n32 and sizes[1] != n32 and sizes[2] > sizes[1]
-    assert lib.rib_set_compute_dtype(h, 7) != 0
+    # (fp32 carries the Winograd-domain filters of the deep 3x3 layers; bf16 carries bf16 copies instead)
+    assert sizes[0] == n32 and sizes[1] != n32
+    assert lib.rib_set_compute_dtype(h, 7) != 0 and lib.rib_set_compute_dtype(h, 2) != 0      # (2 was round 2's retired f32x3 mode)
     lib.rib_destroy(h)
 
 
 def test_plan_flops_and_shape_rules(lib):
     spec, h = host_handle(lib, rib.hsm_gen_config())
-    fl = (C.c_double * 6)()
+    fl = (C.c_double * len(_native.KC_NAMES))()
     for (B, H, W) in [(1, 512, 512), (1, 320, 480), (2, 64, 64), (4, 1024, 1024)]:
         assert lib.rib_forward_flops(h, B, H, W, fl) == 0, lib.rib_last_error(h)
         assert abs(sum(fl) - B * rib.conv_flops(spec, H, W)) < 1e-6 * sum(fl)
@@ -237,8 +236,8 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
                 stale.append((shape, op, ch))
             assert int(ch[10]) >= 1
     assert not stale, stale[:5]
-    # the bf16-storage and f32x3 modes have tables of their own, measured on their own kernels
-    for dtype in ("bf16", "f32x3"):
+    # the bf16-storage mode has a table of its own, measured on its own kernels
+    for dtype in ("bf16",):
         geoms = set()
         for i in range(lib.rib_num_variants()):
             if lib.rib_variant_info(i, g12) == tuning.PREC[dtype]:

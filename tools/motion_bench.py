@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=7, help="timed rounds (>= 5); the median is reported")
     args = ap.parse_args()
     spec = MotionSpec()
     sd = synth.make_state_dict(spec, 0)
@@ -38,15 +39,19 @@ def main():
         for _ in range(5):
             T(src, sm, ps, tgt, tm, pt, rate)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            j, r = T(src, sm, ps, tgt, tm, pt, rate)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.iters
+        # median of `rounds` timed rounds of `iters` forwards each (a single round has shown 3x outliers on a shared box)
+        per_round = []
+        for _ in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                j, r = T(src, sm, ps, tgt, tm, pt, rate)
+            e1.record(); torch.cuda.synchronize()
+            per_round.append(e0.elapsed_time(e1) / args.iters)
+        ms = sorted(per_round)[len(per_round) // 2]
         L = src.shape[-1]
-        row = {"N": N, "L": L, "rate": rate, "gpu_ms": ms, "gpu_frames_per_s": N * L / ms * 1e3,
-               "launches": T._lib.ribm_num_launches(T._h)}
+        row = {"N": N, "L": L, "rate": rate, "gpu_ms": ms, "gpu_ms_min": min(per_round), "gpu_ms_max": max(per_round), "rounds": args.rounds,
+               "gpu_frames_per_s": N * L / ms * 1e3, "launches": T._lib.ribm_num_launches(T._h)}
         if N == 1:
             npf = spec.pos_hidden_dim // 2
             c = [t.cpu() for t in (src, sm, tgt, tm)]

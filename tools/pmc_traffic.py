@@ -14,7 +14,7 @@ import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.prof_ops import plan_names
 
-NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
+NAMES = ("igemm", "spade", "stats", "pool", "eltwise", "pack", "conv_aux")
 
 
 def per_op(d, counter, n):

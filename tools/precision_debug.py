@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug aid for the bf16 / f32x3 precision modes (argv[1]): per-tap error vs the fp32 CPU oracle (in plan order), then the
+"""Debug aid for the bf16 precision mode (argv[1]): per-tap error vs the fp32 CPU oracle (in plan order), then the
 frame error at a few sizes.  Run on the GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -4,8 +4,8 @@
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python3 tools/prof_ops.py --run
     python3 tools/prof_ops.py --report gpurun_out/prof > gpurun_out/prof_ops.txt
 
---run executes W warm-up and K timed forward+blend steps (nothing else launches
-kernels), so dispatches map onto plan ops by position.
+--run executes W warm-up and K timed forward+blend steps - bench.py's default step - and nothing else
+launches kernels, so dispatches map onto plan ops by position.
 """
 import argparse
 import csv
@@ -35,7 +35,6 @@ def plan_names(B, H, W):
         lib.rib_debug_launch_info(h, B, H, W, i, buf, 512)
         name, kclass, grid, tile, flops = buf.value.decode().split("|")
         out.append({"name": name, "class": int(kclass), "grid": grid, "tile": tile, "flops": float(flops)})
-    out.append({"name": "blend", "class": 4, "grid": "", "tile": "", "flops": 0.0})
     return out
 
 
@@ -50,8 +49,7 @@ def run(args):
     label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, args.batch, args.size, args.size, 0)]
     torch.cuda.synchronize()
     for _ in range(args.warmup + args.steps):
-        img, mask = G(label, None, fake, prev)
-        G.blend(img, mask, fake)
+        G.forward_blend(label, None, fake, prev)           # bench.py's step: the mask head writes the fused frame
     torch.cuda.synchronize()
 
 
@@ -79,7 +77,7 @@ def report(args):
     cls = {}
     for o, t in zip(ops, agg):
         cls.setdefault(o["class"], [0, 0.0]); cls[o["class"]][0] += 1; cls[o["class"]][1] += t
-    names = ("igemm", "spade", "stats", "pool", "eltwise", "pack")
+    names = ("igemm", "spade", "stats", "pool", "eltwise", "pack", "conv_aux")
     for k in sorted(cls):
         print("# class %-8s launches %3d  %.1f us" % (names[k], cls[k][0], cls[k][1]))
     print("%-52s %9s %8s  %-14s %s" % ("op", "us", "TFLOP/s", "grid", "tile"))

@@ -31,7 +31,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_I
 done
 echo "[refresh] other shapes and modes"
 rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
-for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype f32x3" "--dtype f32x3 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
+for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
