@@ -1354,6 +1354,41 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Consumer-side InstanceNorm finalize for the light elementwise kernels (round 3).  k_wino_in / k_wino4_in,
+// k_spade_modulate and k_in_add work on CHANNEL SLICES of at most 64 channels per workgroup, so a workgroup can reduce the
+// producer's per-tile partial sums of its own channels (<= STATS_MAX_PARTIALS tiles x 64 channels x 2 doubles, L2-resident)
+// at kernel start instead of reading (scale, shift) arrays written by a k_stats_finalize launch: one dependent launch
+// less per normalised tensor.  Same arithmetic as k_stats_finalize (fp64, fixed order, biased variance, eps 1e-5).
+// 256 threads: thread = (channel j = tid % 64, partial slice q = tid / 64); slice q sums tiles q, q + 4, ...; the four
+// slice sums are added in the order 0..3.  Results in s_sc / s_sh[64]; ends with a barrier.
+// ---------------------------------------------------------------------------------------------
+struct StatSrc {
+  const double* part;      // [B][tiles][2][Cs] or nullptr (then the consumer reads its (scale, shift) arrays)
+  int tiles, Cs;
+  float inv_count;
+  const float* gamma;      // IN affine of the producing layer (indexed by channel) or nullptr
+  const float* beta;
+};
+
+__device__ __forceinline__ void block_stats_64(const StatSrc& s, int n, int c0, int nch, double* red /* [4][64][2] */,
+                                               float* s_sc, float* s_sh) {
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  double a1 = 0.0, a2 = 0.0;
+  if (j < nch) stats_from_partials(s.part + (size_t)n * s.tiles * 2 * s.Cs, s.tiles, s.Cs, c0 + j, q, 4, a1, a2);
+  red[(q * 64 + j) * 2] = a1; red[(q * 64 + j) * 2 + 1] = a2;
+  __syncthreads();
+  if (q == 0 && j < nch) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t1 += red[(k * 64 + j) * 2]; t2 += red[(k * 64 + j) * 2 + 1]; }
+    float sc, sh;
+    scale_shift_of(t1, t2, s.inv_count, s.gamma ? s.gamma[c0 + j] : 1.f, s.beta ? s.beta[c0 + j] : 0.f, sc, sh);
+    s_sc[j] = sc; s_sh[j] = sh;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the 3x3 stride-1 convolutions on the <= 64x64 maps (round 2).  At batch 1 those layers
 // cannot fill 256 CUs (a 32x32 map is 8 spatial tiles) and run as split-K launches of short workgroups; they are half
 // of the frame.  In the Winograd domain the convolution is 16 independent GEMMs [2x2-tiles x Cin] . [Cin x Cout] - one
@@ -1366,27 +1401,55 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
 // and M (4x the activation each) stay in L2 / the memory-side cache at these sizes.  fp32 throughout: the transforms
 // only add and halve, max |diff| to the direct kernel ~3e-6 on O(1) outputs (round 1's probe).
 // Layouts: V [B*16][tilesY][tilesX][Cin], M [B*16][tilesY][tilesX][CoutPad], sample index = n*16 + xi, xi = 4*row + col.
+// Work split of the transforms (round 3): a workgroup owns a slice of 64 channels (16 float4 lanes) and 16 (tile, row)
+// units per pass; blockIdx.x = unit block * nslices + slice.  The output transforms emit ONE statistics partial per unit
+// block (<= 64 of them), so that the consumer of the normalised tensor can reduce them itself (block_stats_64).
 // ---------------------------------------------------------------------------------------------
 struct WinoInParams {
   const float* x; int H, W, xC, Cin;        // input activation [B][H][W][xC], Cin channels used (multiple of 4)
   const float* pro_scale; const float* pro_shift; int pro_ld, pro_lrelu;   // optional prologue (as k_igemm's)
+  StatSrc st;                                // consumer-side finalize: replaces pro_scale / pro_shift when st.part != nullptr
   float* v; int tilesY, tilesX;
+  int nslices, ublocks;                      // grid.x = ublocks * nslices (channel slices of 64)
 };
 
+// prologue constants of this thread's four channels: from the workgroup's own reduction, from the arrays, or identity
+__device__ __forceinline__ void wino_in_prologue(const WinoInParams& p, int n, int slice, int c4, bool cok, double* red, float* s_sc,
+                                                 float* s_sh, float4& sc, float4& sh, bool& aff) {
+  sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  aff = false;
+  if (p.st.part) {
+    block_stats_64(p.st, n, slice * 64, min(64, p.Cin - slice * 64), red, s_sc, s_sh);
+    const int l = (threadIdx.x & 15) * 4;
+    sc = make_float4(s_sc[l], s_sc[l + 1], s_sc[l + 2], s_sc[l + 3]);
+    sh = make_float4(s_sh[l], s_sh[l + 1], s_sh[l + 2], s_sh[l + 3]);
+    aff = true;
+  } else if (p.pro_scale && cok) {
+    sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+    sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+    aff = true;
+  }
+}
+
+#define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
+#define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
+
 __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
-  // thread = (tile, 4 channels, row r of the transformed tile): these maps are small (256 .. 4096 tiles), a thread per
-  // whole tile left half of the chip idle and the kernel on its load latency; a row needs two input rows (8 loads)
+  // thread = ((tile, row r of the transformed tile), 4 channels of the slice): a row needs two input rows (8 loads)
+  __shared__ double red[4 * 64 * 2];
+  __shared__ float s_sc[64], s_sh[64];
   const int c4n = p.Cin / 4;
   const int n = blockIdx.y;
+  const int slice = blockIdx.x % p.nslices, ub = blockIdx.x / p.nslices;
+  const int c4 = slice * 16 + (threadIdx.x & 15);
+  const bool cok = c4 < c4n;
   const int ntiles = p.tilesY * p.tilesX;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n * 4; i += gridDim.x * 256) {
-    const int c4 = i % c4n, r = (i / c4n) & 3, tile = i / (c4n * 4);
+  float4 sc, sh; bool aff;
+  wino_in_prologue(p, n, slice, c4, cok, red, s_sc, s_sh, sc, sh, aff);
+  if (!cok) return;
+  for (int u = ub * 16 + (threadIdx.x >> 4); u < ntiles * 4; u += p.ublocks * 16) {
+    const int r = u & 3, tile = u >> 2;
     const int ty = tile / p.tilesX, tx = tile % p.tilesX;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.pro_scale) {
-      sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
-      sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
-    }
     // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: row r of B^T d is d[ia] + sg * d[ib]
     const int ia = r == 0 ? 0 : (r == 2 ? 2 : 1), ib = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
     const float sg = r == 1 ? 1.f : -1.f;
@@ -1407,15 +1470,13 @@ __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
       for (int a = 0; a < 2; ++a) {
         const int iy = 2 * ty - 1 + (a ? ib : ia), ix = 2 * tx - 1 + q;
         float4 w = d[a][q];
-        if (p.pro_scale) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
+        if (aff) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
         if (p.pro_lrelu) w = lrelu4(w);
         if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
         v[a] = w;
       }
       t[q] = make_float4(v[0].x + sg * v[1].x, v[0].y + sg * v[1].y, v[0].z + sg * v[1].z, v[0].w + sg * v[1].w);
     }
-#define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
-#define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
     const size_t plane = (size_t)ntiles * p.Cin;              // one position's [tiles][Cin] matrix
     float* vb = p.v + (size_t)n * 16 * plane + (size_t)tile * p.Cin + c4 * 4;
     *reinterpret_cast<float4*>(vb + (size_t)(r * 4 + 0) * plane) = RIB_F4_SUB(t[0], t[2]);
@@ -1431,80 +1492,89 @@ struct WinoOutParams {
   float* y; int yC, yoff, Cout, Hout, Wout;
   int act;
   const float* res; int resC;
-  double* stat_part; int blocks;                  // [B][blocks][2][CoutPad]
+  double* stat_part;                              // [B][ublocks][2][CoutPad]: one partial per unit block
+  int nslices, ublocks;                           // grid.x = ublocks * nslices (channel slices of 64)
 };
 
-// grid (blocks, B); thread = (tile slot, output row r of the 2x2 tile, 4 channels); a block covers 128 / (CoutPad/4) tiles
-__global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
-  __shared__ __attribute__((aligned(16))) double red[2][256][4];
-  const int c4n = p.CoutPad / 4;
-  const int slots2 = 256 / c4n;                  // (tile, row) pairs per block
-  const int c4 = threadIdx.x % c4n, sr = threadIdx.x / c4n;
-  const int r = sr & 1, slot = sr >> 1;
-  const int n = blockIdx.y;
-  const int ntiles = p.tilesY * p.tilesX;
-  const int tile = blockIdx.x * (slots2 / 2) + slot;
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  if (tile < ntiles && sr < slots2) {
-    const size_t plane = (size_t)ntiles * p.CoutPad;
-    const float* mb = p.m + (size_t)n * 16 * plane + (size_t)tile * p.CoutPad + c4 * 4;
-    // A^T = [1 1 1 0; 0 1 -1 -1]: output row r combines the rows r, r+1, r+2 of M: (+, +, +) for r = 0, (+, -, -) for r = 1
-    float4 mm[3][4];
+// the statistics partial of one (unit block, channel slice) workgroup: thread (unit slot us = tid >> 4, float4 lane cl = tid & 15)
+// holds s1 / s2 of its four channels; the 16 unit slots are summed in a fixed order by one thread per channel
+__device__ __forceinline__ void wino_out_partials(double (*red)[256][4], const double s1[4], const double s2[4], double* stat_part,
+                                                  int n, int ublocks, int ub, int slice, int CoutPad) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) mm[a][q] = *reinterpret_cast<const float4*>(mb + (size_t)((r + a) * 4 + q) * plane);
-    const float sg = r ? -1.f : 1.f;
-    float4 u[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      u[q] = make_float4(mm[0][q].x + sg * (mm[1][q].x + mm[2][q].x), mm[0][q].y + sg * (mm[1][q].y + mm[2][q].y),
-                         mm[0][q].z + sg * (mm[1][q].z + mm[2][q].z), mm[0][q].w + sg * (mm[1][q].w + mm[2][q].w));
-    float4 yv[2];
-    yv[0] = RIB_F4_ADD(RIB_F4_ADD(u[0], u[1]), u[2]);
-    yv[1] = RIB_F4_SUB(RIB_F4_SUB(u[1], u[2]), u[3]);
-    const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
-    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
-    const int oy = 2 * ty + r;
-    float rr[2][4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int cy = min(oy, p.Hout - 1), cx = min(2 * tx + q, p.Wout - 1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int ox = 2 * tx + q;
-      const bool inb = oy < p.Hout && ox < p.Wout;
-      const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = apply_act(v4[e] + rr[q][e], p.act);
-        const bool ok = inb && c4 * 4 + e < p.Cout;
-        if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
-        t = ok ? t : 0.f;
-        s1[e] += (double)t; s2[e] += (double)t * (double)t;
-      }
-    }
-  }
-  if (p.stat_part) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
-      const int g = c / 4, e = c % 4;
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = slice * 64 + threadIdx.x;
+    if (c < CoutPad) {
+      const int g = threadIdx.x >> 2, e = threadIdx.x & 3;
       double a1 = 0.0, a2 = 0.0;
-      for (int s = 0; s < slots2; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
-      double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { a1 += red[0][s * 16 + g][e]; a2 += red[1][s * 16 + g][e]; }
+      double* dst = stat_part + (((size_t)n * ublocks + ub) * 2) * CoutPad;
       dst[c] = a1;
-      dst[p.CoutPad + c] = a2;
+      dst[CoutPad + c] = a2;
     }
   }
 }
-#undef RIB_F4_SUB
-#undef RIB_F4_ADD
+
+// grid (ublocks * nslices, B); thread = ((tile, output row r of the 2x2 tile), 4 channels of the slice)
+__global__ __launch_bounds__(256) void k_wino_out(const WinoOutParams p) {
+  __shared__ __attribute__((aligned(16))) double red[2][256][4];
+  const int c4n = p.CoutPad / 4;
+  const int slice = blockIdx.x % p.nslices, ub = blockIdx.x / p.nslices;
+  const int c4 = slice * 16 + (threadIdx.x & 15);
+  const int n = blockIdx.y;
+  const int ntiles = p.tilesY * p.tilesX;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c4 < c4n) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+    const size_t plane = (size_t)ntiles * p.CoutPad;
+    for (int u = ub * 16 + (threadIdx.x >> 4); u < ntiles * 2; u += p.ublocks * 16) {
+      const int r = u & 1, tile = u >> 1;
+      const float* mb = p.m + (size_t)n * 16 * plane + (size_t)tile * p.CoutPad + c4 * 4;
+      // A^T = [1 1 1 0; 0 1 -1 -1]: output row r combines the rows r, r+1, r+2 of M: (+, +, +) for r = 0, (+, -, -) for r = 1
+      float4 mm[3][4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mm[a][q] = *reinterpret_cast<const float4*>(mb + (size_t)((r + a) * 4 + q) * plane);
+      const float sg = r ? -1.f : 1.f;
+      float4 uu[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        uu[q] = make_float4(mm[0][q].x + sg * (mm[1][q].x + mm[2][q].x), mm[0][q].y + sg * (mm[1][q].y + mm[2][q].y),
+                            mm[0][q].z + sg * (mm[1][q].z + mm[2][q].z), mm[0][q].w + sg * (mm[1][q].w + mm[2][q].w));
+      float4 yv[2];
+      yv[0] = RIB_F4_ADD(RIB_F4_ADD(uu[0], uu[1]), uu[2]);
+      yv[1] = RIB_F4_SUB(RIB_F4_SUB(uu[1], uu[2]), uu[3]);
+      const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+      const int oy = 2 * ty + r;
+      float rr[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int cy = min(oy, p.Hout - 1), cx = min(2 * tx + q, p.Wout - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ox = 2 * tx + q;
+        const bool inb = oy < p.Hout && ox < p.Wout;
+        const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = apply_act(v4[e] + rr[q][e], p.act);
+          const bool ok = inb && c4 * 4 + e < p.Cout;
+          if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
+          t = ok ? t : 0.f;
+          s1[e] += (double)t; s2[e] += (double)t * (double)t;
+        }
+      }
+    }
+  }
+  if (p.stat_part) wino_out_partials(red, s1, s2, p.stat_part, n, p.ublocks, ub, slice, p.CoutPad);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Winograd F(4x4, 3x3): 36 positions, 4x4 outputs per tile, 1/4 of the nine-tap multiplications (F(2x2): 4/9) and 2.25
@@ -1528,19 +1598,22 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc) {
 }
 __device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
 
-// thread = (tile, transformed row r, 4 channels); row r of B^T d needs the 3 or 4 input rows with a non-zero coefficient
+// thread = ((tile, transformed row r), 4 channels of the slice); row r of B^T d needs the 3 or 4 input rows with a non-zero coefficient
 __global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
+  __shared__ double red[4 * 64 * 2];
+  __shared__ float s_sc[64], s_sh[64];
   const int c4n = p.Cin / 4;
   const int n = blockIdx.y;
+  const int slice = blockIdx.x % p.nslices, ub = blockIdx.x / p.nslices;
+  const int c4 = slice * 16 + (threadIdx.x & 15);
+  const bool cok = c4 < c4n;
   const int ntiles = p.tilesY * p.tilesX;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntiles * c4n * 6; i += gridDim.x * 256) {
-    const int c4 = i % c4n, r = (i / c4n) % 6, tile = i / (c4n * 6);
+  float4 sc, sh; bool aff;
+  wino_in_prologue(p, n, slice, c4, cok, red, s_sc, s_sh, sc, sh, aff);
+  if (!cok) return;
+  for (int u = ub * 16 + (threadIdx.x >> 4); u < ntiles * 6; u += p.ublocks * 16) {
+    const int r = u % 6, tile = u / 6;
     const int ty = tile / p.tilesX, tx = tile % p.tilesX;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.pro_scale) {
-      sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
-      sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
-    }
     // rows with a non-zero coefficient: r = 0 -> {0, 2, 4}; r = 1..4 -> {1, 2, 3, 4}; r = 5 -> {1, 3, 5}
     const int a0 = r == 0 ? 0 : 1, da = (r == 0 || r == 5) ? 2 : 1, na = (r == 0 || r == 5) ? 3 : 4;
     float4 d[4][6];
@@ -1564,7 +1637,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
       for (int q = 0; q < 6; ++q) {
         const int ix = 4 * tx - 1 + q;
         float4 w = d[k][q];
-        if (p.pro_scale) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
+        if (aff) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
         if (p.pro_lrelu) w = lrelu4(w);
         if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
         t[q] = f4_fma(coef, w, t[q]);
@@ -1578,127 +1651,144 @@ __global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
     const float4 ev1 = f4_fma(-9.f / 4, t[2], t[4]), od1 = f4_fma(-27.f / 16, t[1], f4_scale(3.f / 4, t[3]));
     const float4 ev2 = f4_fma(-9.f / 16, t[2], t[4]), od2 = f4_fma(-27.f / 32, t[1], f4_scale(3.f / 2, t[3]));
     *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 0) * plane) = f4_fma(81.f / 64, t[0], e24);
-    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 1) * plane) = make_float4(ev1.x + od1.x, ev1.y + od1.y, ev1.z + od1.z, ev1.w + od1.w);
-    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 2) * plane) = make_float4(ev1.x - od1.x, ev1.y - od1.y, ev1.z - od1.z, ev1.w - od1.w);
-    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 3) * plane) = make_float4(ev2.x + od2.x, ev2.y + od2.y, ev2.z + od2.z, ev2.w + od2.w);
-    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 4) * plane) = make_float4(ev2.x - od2.x, ev2.y - od2.y, ev2.z - od2.z, ev2.w - od2.w);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 1) * plane) = RIB_F4_ADD(ev1, od1);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 2) * plane) = RIB_F4_SUB(ev1, od1);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 3) * plane) = RIB_F4_ADD(ev2, od2);
+    *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 4) * plane) = RIB_F4_SUB(ev2, od2);
     *reinterpret_cast<float4*>(vb + (size_t)(r * 6 + 5) * plane) = f4_fma(81.f / 64, t[1], o13);
   }
 }
 
-// grid (blocks, B); thread = ((tile, output row r of the 4x4 tile), 4 channels); a block covers 256 / (CoutPad/4) such rows
+// grid (ublocks * nslices, B); thread = ((tile, output row r of the 4x4 tile), 4 channels of the slice)
 __global__ __launch_bounds__(256) void k_wino4_out(const WinoOutParams p) {
   __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.CoutPad / 4;
-  const int upb = 256 / c4n;                     // (tile, row) units per block
-  const int c4 = threadIdx.x % c4n, us = threadIdx.x / c4n;
+  const int slice = blockIdx.x % p.nslices, ub = blockIdx.x / p.nslices;
+  const int c4 = slice * 16 + (threadIdx.x & 15);
   const int n = blockIdx.y;
   const int ntiles = p.tilesY * p.tilesX;
-  const int unit = blockIdx.x * upb + us;
-  const int tile = unit >> 2, r = unit & 3;
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  if (tile < ntiles) {
-    const size_t plane = (size_t)ntiles * p.CoutPad;
-    const float* mb = p.m + (size_t)n * 36 * plane + (size_t)tile * p.CoutPad + c4 * 4;
-    // u[q] = sum_a A^T[r][a] M[a][q]: rows 1..4 always, row 0 for r = 0, row 5 for r = 3
-    float4 u[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) u[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ax = r == 0 ? 0 : 5;               // the extra row (coefficient 1 for r = 0 / 3, unused otherwise)
-    const float cx_ = (r == 0 || r == 3) ? 1.f : 0.f;
-    float4 mm[5][6];
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-      for (int q = 0; q < 6; ++q) mm[k][q] = *reinterpret_cast<const float4*>(mb + (size_t)((k < 4 ? k + 1 : ax) * 6 + q) * plane);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const float coef = k < 4 ? kWino4AT[r][k + 1] : cx_;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) u[q] = f4_fma(coef, mm[k][q], u[q]);
-    }
-    // y[j] = sum_q A^T[j][q] u[q]
-    const float4 s12 = make_float4(u[1].x + u[2].x, u[1].y + u[2].y, u[1].z + u[2].z, u[1].w + u[2].w);
-    const float4 d12 = make_float4(u[1].x - u[2].x, u[1].y - u[2].y, u[1].z - u[2].z, u[1].w - u[2].w);
-    const float4 s34 = make_float4(u[3].x + u[4].x, u[3].y + u[4].y, u[3].z + u[4].z, u[3].w + u[4].w);
-    const float4 d34 = make_float4(u[3].x - u[4].x, u[3].y - u[4].y, u[3].z - u[4].z, u[3].w - u[4].w);
-    float4 yv[4];
-    yv[0] = make_float4(u[0].x + s12.x + s34.x, u[0].y + s12.y + s34.y, u[0].z + s12.z + s34.z, u[0].w + s12.w + s34.w);
-    yv[1] = f4_fma(3.f / 4, d12, f4_scale(3.f / 2, d34));
-    yv[2] = f4_fma(9.f / 16, s12, f4_scale(9.f / 4, s34));
-    yv[3] = f4_fma(27.f / 64, d12, f4_fma(27.f / 8, d34, u[5]));
+  if (c4 < c4n) {
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
-    const int ty = tile / p.tilesX, tx = tile % p.tilesX;
-    const int oy = 4 * ty + r;
-    float rr[4][4];
+    const size_t plane = (size_t)ntiles * p.CoutPad;
+    for (int unit = ub * 16 + (threadIdx.x >> 4); unit < ntiles * 4; unit += p.ublocks * 16) {
+      const int tile = unit >> 2, r = unit & 3;
+      const float* mb = p.m + (size_t)n * 36 * plane + (size_t)tile * p.CoutPad + c4 * 4;
+      // u[q] = sum_a A^T[r][a] M[a][q]: rows 1..4 always, row 0 for r = 0, row 5 for r = 3
+      float4 u[6];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cy = min(oy, p.Hout - 1), cx = min(4 * tx + q, p.Wout - 1);
+      for (int q = 0; q < 6; ++q) u[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ax = r == 0 ? 0 : 5;               // the extra row (coefficient 1 for r = 0 / 3, unused otherwise)
+      const float cx_ = (r == 0 || r == 3) ? 1.f : 0.f;
+      float4 mm[5][6];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
-    }
+      for (int k = 0; k < 5; ++k)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ox = 4 * tx + q;
-      const bool inb = oy < p.Hout && ox < p.Wout;
-      const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
+        for (int q = 0; q < 6; ++q) mm[k][q] = *reinterpret_cast<const float4*>(mb + (size_t)((k < 4 ? k + 1 : ax) * 6 + q) * plane);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = apply_act(v4[e] + rr[q][e], p.act);
-        const bool ok = inb && c4 * 4 + e < p.Cout;
-        if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
-        t = ok ? t : 0.f;
-        s1[e] += (double)t; s2[e] += (double)t * (double)t;
+      for (int k = 0; k < 5; ++k) {
+        const float coef = k < 4 ? kWino4AT[r][k + 1] : cx_;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u[q] = f4_fma(coef, mm[k][q], u[q]);
+      }
+      // y[j] = sum_q A^T[j][q] u[q]
+      const float4 s12 = RIB_F4_ADD(u[1], u[2]);
+      const float4 d12 = RIB_F4_SUB(u[1], u[2]);
+      const float4 s34 = RIB_F4_ADD(u[3], u[4]);
+      const float4 d34 = RIB_F4_SUB(u[3], u[4]);
+      float4 yv[4];
+      yv[0] = make_float4(u[0].x + s12.x + s34.x, u[0].y + s12.y + s34.y, u[0].z + s12.z + s34.z, u[0].w + s12.w + s34.w);
+      yv[1] = f4_fma(3.f / 4, d12, f4_scale(3.f / 2, d34));
+      yv[2] = f4_fma(9.f / 16, s12, f4_scale(9.f / 4, s34));
+      yv[3] = f4_fma(27.f / 64, d12, f4_fma(27.f / 8, d34, u[5]));
+      const int ty = tile / p.tilesX, tx = tile % p.tilesX;
+      const int oy = 4 * ty + r;
+      float rr[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cy = min(oy, p.Hout - 1), cx = min(4 * tx + q, p.Wout - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rr[q][e] = p.res ? p.res[(((size_t)n * p.Hout + cy) * p.Wout + cx) * p.resC + min(c4 * 4 + e, p.resC - 1)] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ox = 4 * tx + q;
+        const bool inb = oy < p.Hout && ox < p.Wout;
+        const float v4[4] = {yv[q].x + bv.x, yv[q].y + bv.y, yv[q].z + bv.z, yv[q].w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = apply_act(v4[e] + rr[q][e], p.act);
+          const bool ok = inb && c4 * 4 + e < p.Cout;
+          if (ok) p.y[(((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + c4 * 4 + e] = t;
+          t = ok ? t : 0.f;
+          s1[e] += (double)t; s2[e] += (double)t * (double)t;
+        }
       }
     }
   }
-  if (p.stat_part) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < p.CoutPad; c += 256) {
-      const int g = c / 4, e = c % 4;
-      double a1 = 0.0, a2 = 0.0;
-      for (int s = 0; s < upb; ++s) { a1 += red[0][s * c4n + g][e]; a2 += red[1][s * c4n + g][e]; }
-      double* dst = p.stat_part + (((size_t)n * p.blocks + blockIdx.x) * 2) * p.CoutPad;
-      dst[c] = a1;
-      dst[p.CoutPad + c] = a2;
-    }
-  }
+  if (p.stat_part) wino_out_partials(red, s1, s2, p.stat_part, n, p.ublocks, ub, slice, p.CoutPad);
 }
+#undef RIB_F4_SUB
+#undef RIB_F4_ADD
 
 // ---------------------------------------------------------------------------------------------
 // k_spade_modulate: second half of an UNFUSED SPADE (used where the map is small and the fused
-// kernel cannot fill the chip): the gamma/beta 1x1 GEMM ran as a (split-K) convolution into
-// slab [S][B][HW][npad] with the fused kernel's column layout ([gamma(32) | beta(32)] per 32
-// virtual channels, virtual channel v = set*C + c); this kernel sums the slices and applies
+// kernel cannot fill the chip).  The gamma/beta 1x1 GEMM ran as a convolution into a slab
+// [S][B][HW][slab_ld] - either its own (split-K) launch or, since round 3, ONE launch per condition level that
+// computes the gamma/beta of every SPADE of that level (Builder::cond_level_gemm: the filters of the level's SPADE
+// groups are concatenated along N; this group's columns start at col0) - in the fused kernel's column layout
+// ([gamma(32) | beta(32)] per 32 virtual channels, virtual channel v = set*C + c); this kernel sums the slices and applies
 //   out_set = act_set( (x*scale + shift) * (1 + gamma) + beta )
-// thread = (pixel, 4 virtual channels); grid (blocks, B).
+// grid (pblocks * nslices, B): a workgroup owns a slice of 64 virtual channels (16 float4 lanes) and 16 pixels per pass,
+// so that it can take (scale, shift) of its 64 channels from the producer's partials itself (block_stats_64).
 // ---------------------------------------------------------------------------------------------
 struct ModulateParams {
-  const float* slab; int ksplit, B, npad;
-  const float* bias;
+  const float* slab; int ksplit, B, slab_ld, col0;
+  const float* bias;       // this group's [npad] bias vector
   const float* xm; int xmC, xm_ups;
   const float* m_scale; const float* m_shift; int m_ld;
+  StatSrc st;              // replaces m_scale / m_shift when st.part != nullptr (needs C % 64 == 0: a slice stays inside one set)
   int C, nsets;
   float* ys0; float* ys1; int act0, act1;
   int Hout, Wout;
+  int nslices, pblocks;
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) {
+  __shared__ double red[4 * 64 * 2];
+  __shared__ float s_sc[64], s_sh[64];
   const int v4n = p.nsets * p.C / 4;
   const int n = blockIdx.y;
+  const int slice = blockIdx.x % p.nslices, pb = blockIdx.x / p.nslices;
+  const int v4 = slice * 16 + (threadIdx.x & 15);
   const int npix = p.Hout * p.Wout;
-  const size_t total = (size_t)npix * v4n;
-  const size_t sstride = (size_t)p.B * npix * p.npad;
+  const size_t sstride = (size_t)p.B * npix * p.slab_ld;
   const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int v = (int)(i % v4n) * 4;
-    const int pix = (int)(i / v4n);
-    const int colg = (v / 32) * 64 + (v % 32);
-    const float* src = p.slab + ((size_t)n * npix + pix) * p.npad + colg;
+  const int v = v4 * 4;
+  const int set = v >= p.C ? 1 : 0;
+  const int c = v - set * p.C;
+  float4 sc, sh;
+  if (p.st.part) {
+    const int v0 = slice * 64, c0 = v0 >= p.C ? v0 - p.C : v0;
+    block_stats_64(p.st, n, c0, min(64, p.C - c0), red, s_sc, s_sh);
+    const int l = (threadIdx.x & 15) * 4;
+    sc = make_float4(s_sc[l], s_sc[l + 1], s_sc[l + 2], s_sc[l + 3]);
+    sh = make_float4(s_sh[l], s_sh[l + 1], s_sh[l + 2], s_sh[l + 3]);
+  }
+  if (v4 >= v4n) return;
+  if (!p.st.part) {
+    sc = *reinterpret_cast<const float4*>(p.m_scale + (size_t)n * p.m_ld + c);
+    sh = *reinterpret_cast<const float4*>(p.m_shift + (size_t)n * p.m_ld + c);
+  }
+  const int colg = (v / 32) * 64 + (v % 32);
+  const float4 bg = *reinterpret_cast<const float4*>(p.bias + colg);
+  const float4 bb = *reinterpret_cast<const float4*>(p.bias + colg + 32);
+  const int act = set ? p.act1 : p.act0;
+  float* yout = set ? p.ys1 : p.ys0;
+  for (int pix = pb * 16 + (threadIdx.x >> 4); pix < npix; pix += p.pblocks * 16) {
+    const float* src = p.slab + ((size_t)n * npix + pix) * p.slab_ld + p.col0 + colg;
     float4 g = *reinterpret_cast<const float4*>(src);
     float4 b = *reinterpret_cast<const float4*>(src + 32);
 #pragma unroll 4
@@ -1708,22 +1798,14 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
       g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
     }
-    const float4 bg = *reinterpret_cast<const float4*>(p.bias + colg);
-    const float4 bb = *reinterpret_cast<const float4*>(p.bias + colg + 32);
-    const int set = v >= p.C ? 1 : 0;
-    const int c = v - set * p.C;
     const int oy = pix / p.Wout, ox = pix % p.Wout;
     const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
     const float4 x = ld_act4<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
-    const float4 sc = *reinterpret_cast<const float4*>(p.m_scale + (size_t)n * p.m_ld + c);
-    const float4 sh = *reinterpret_cast<const float4*>(p.m_shift + (size_t)n * p.m_ld + c);
-    const int act = set ? p.act1 : p.act0;
     float4 o;
     o.x = apply_act((x.x * sc.x + sh.x) * (1.f + (g.x + bg.x)) + (b.x + bb.x), act);
     o.y = apply_act((x.y * sc.y + sh.y) * (1.f + (g.y + bg.y)) + (b.y + bb.y), act);
     o.z = apply_act((x.z * sc.z + sh.z) * (1.f + (g.z + bg.z)) + (b.z + bb.z), act);
     o.w = apply_act((x.w * sc.w + sh.w) * (1.f + (g.w + bg.w)) + (b.w + bb.w), act);
-    float* yout = set ? p.ys1 : p.ys0;
     st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
   }
 }
@@ -1796,6 +1878,8 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
 // ---------------------------------------------------------------------------------------------
 // k_in_add: mask-network residual join (Res2dBlock 'CNACN', PGNR/models/generator.py:465-476):
 //   out = IN_affine(t1) + (ts ? IN_affine(ts) : xres)      float4 over [B][HW][C]
+// grid (pblocks * nslices, B): channel slices of 64 as k_spade_modulate, for the same reason (st1 / sts: the partials
+// of the two producers instead of their (scale, shift) arrays).
 // ---------------------------------------------------------------------------------------------
 struct InAddParams {
   const float* t1; const float* sc1; const float* sh1;
@@ -1804,24 +1888,36 @@ struct InAddParams {
   float* out;
   int C, HW;
   int ld;   // leading dim of the scale/shift arrays
+  StatSrc st1, sts;
+  int nslices, pblocks;
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
+  __shared__ double red[4 * 64 * 2];
+  __shared__ float s_sc[2][64], s_sh[2][64];
   const int c4n = p.C / 4;
-  const size_t total = (size_t)p.HW * c4n;
   const int n = blockIdx.y;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c4 = (int)(i % c4n);
-    const size_t e = ((size_t)n * p.HW) * p.C + i * 4;
+  const int slice = blockIdx.x % p.nslices, pb = blockIdx.x / p.nslices;
+  const int c4 = slice * 16 + (threadIdx.x & 15);
+  const int nch = min(64, p.C - slice * 64);
+  if (p.st1.part) block_stats_64(p.st1, n, slice * 64, nch, red, s_sc[0], s_sh[0]);
+  if (p.ts && p.sts.part) block_stats_64(p.sts, n, slice * 64, nch, red, s_sc[1], s_sh[1]);
+  if (c4 >= c4n) return;
+  const int l = (threadIdx.x & 15) * 4;
+  float4 s, t, s2 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = s2;
+  if (p.st1.part) { s = make_float4(s_sc[0][l], s_sc[0][l + 1], s_sc[0][l + 2], s_sc[0][l + 3]); t = make_float4(s_sh[0][l], s_sh[0][l + 1], s_sh[0][l + 2], s_sh[0][l + 3]); }
+  else { s = *reinterpret_cast<const float4*>(p.sc1 + (size_t)n * p.ld + c4 * 4); t = *reinterpret_cast<const float4*>(p.sh1 + (size_t)n * p.ld + c4 * 4); }
+  if (p.ts) {
+    if (p.sts.part) { s2 = make_float4(s_sc[1][l], s_sc[1][l + 1], s_sc[1][l + 2], s_sc[1][l + 3]); t2 = make_float4(s_sh[1][l], s_sh[1][l + 1], s_sh[1][l + 2], s_sh[1][l + 3]); }
+    else { s2 = *reinterpret_cast<const float4*>(p.scs + (size_t)n * p.ld + c4 * 4); t2 = *reinterpret_cast<const float4*>(p.shs + (size_t)n * p.ld + c4 * 4); }
+  }
+  for (int pix = pb * 16 + (threadIdx.x >> 4); pix < p.HW; pix += p.pblocks * 16) {
+    const size_t e = ((size_t)n * p.HW + pix) * p.C + c4 * 4;
     const float4 a = ld_act4<BF16>(p.t1, e);
-    const float4 s = *reinterpret_cast<const float4*>(p.sc1 + (size_t)n * p.ld + c4 * 4);
-    const float4 t = *reinterpret_cast<const float4*>(p.sh1 + (size_t)n * p.ld + c4 * 4);
     float4 o = make_float4(a.x * s.x + t.x, a.y * s.y + t.y, a.z * s.z + t.z, a.w * s.w + t.w);
     if (p.ts) {
       const float4 b = ld_act4<BF16>(p.ts, e);
-      const float4 s2 = *reinterpret_cast<const float4*>(p.scs + (size_t)n * p.ld + c4 * 4);
-      const float4 t2 = *reinterpret_cast<const float4*>(p.shs + (size_t)n * p.ld + c4 * 4);
       o.x += b.x * s2.x + t2.x; o.y += b.y * s2.y + t2.y; o.z += b.z * s2.z + t2.z; o.w += b.w * s2.w + t2.w;
     } else {
       const float4 b = ld_act4<BF16>(p.xres, e);

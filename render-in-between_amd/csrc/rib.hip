@@ -128,6 +128,10 @@ struct SpadeGroup {   // one SPADE launch: 1 or 2 modulations sharing the normal
   // 16 modulated channels in all (C = 16, one set): a second copy in [gamma(16) | beta(16)] order, one 32-column
   // fragment instead of two half-empty ones (fp32 SPADE variants with NF = 1)
   size_t w1_off = 0, b1_off = 0;
+  // condition level (index of the ref_embedding map this SPADE reads) and first column of this group inside the level's
+  // concatenated gamma/beta filter matrix [sum of npad][cond] (the groups of a level are laid out back to back in the blob,
+  // in execution order, so that ONE 1x1 GEMM on the level's map can produce the gamma/beta of all of them: cond_level_gemm)
+  int level = 0, col0 = 0;
 };
 
 struct Cfg {
@@ -383,6 +387,8 @@ struct Op {
   IgemmParams ip;   // scalar fields pre-filled; pointers resolved from the PRefs below
   PRef x, pro_scale, pro_shift, w, bias, y, res, y_nchw, stat, xm, m_scale, m_shift, ys0, ys1, slab, x2, w2;
   PRef m_part;   // consumer-side InstanceNorm finalize in the SPADE epilogue (IgemmParams)
+  // consumer-side finalize in k_wino_in / k_spade_modulate (slot 0) and k_in_add (slots 0, 1): the StatSrc pointers
+  PRef st_part[2], st_gamma[2], st_beta[2];
   // split-K epilogue
   SplitEpiParams sp; PRef s_slab, s_bias, s_y, s_res, s_stat;
   // unfused SPADE modulate
@@ -459,6 +465,7 @@ struct rib_handle {
   std::map<std::string, int> tensor_index;
   std::vector<SpadeGroup> spades;
   std::map<std::string, int> spade_index;
+  std::map<int, std::vector<int>> level_groups;   // condition level -> its SPADE groups (indices into spades), execution order
   float* d_blob = nullptr;
   size_t d_blob_floats = 0;      // allocated size (the bf16 storage mode carries bf16 filter copies: a larger blob)
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
@@ -547,21 +554,40 @@ void assign_weight_layout(rib_handle* h) {
         h->conv_index.count(c.name.substr(0, c.name.size() - 1) + "s"))
       c.fb_off = take(c.coutp);
   }
-  // SPADE groups: block_0 (+ block_s when the shortcut is learned) share one launch
-  for (auto& c : h->convs) {
-    if (!c.used || !c.spade_cond) continue;
-    const std::string blk = c.name.substr(0, c.name.rfind(".conv_block_"));
-    const std::string which = c.name.substr(c.name.size() - 1);
-    if (which == "s") continue;   // folded into the "0" group
-    SpadeGroup sg;
-    sg.C = c.cin; sg.Cp = h->padc(c.cin); sg.cond = c.spade_cond;
-    sg.nsets = (which == "0" && h->conv_index.count(blk + ".conv_block_s")) ? 2 : 1;
-    sg.key = blk + "." + which;
-    sg.npad = (sg.nsets * sg.Cp + 31) / 32 * 64;
-    sg.w_off = take((size_t)sg.npad * h->padc(sg.cond));
-    sg.b_off = take(sg.npad);
-    h->spade_index[sg.key] = (int)h->spades.size();
-    h->spades.push_back(sg);
+  // SPADE groups: block_0 (+ block_s when the shortcut is learned) share one launch.  Created level by level, in the
+  // order the forward runs them (down_i, res_*, up_i), and their filters taken back to back: the filter matrices of a
+  // level's groups form ONE [sum npad][cond] matrix in the blob (SpadeGroup::col0)
+  {
+    const rib_config& gc = h->g.c;
+    const int D = gc.num_down_img;
+    std::vector<std::pair<std::string, int>> blocks;      // (block name, condition level) in execution order
+    for (int i = 0; i <= D; ++i) blocks.push_back({"down_" + std::to_string(i), std::min(gc.emb_down, i)});
+    for (int i = 0; i < h->g.num_res_blocks(); ++i) blocks.push_back({"res_" + std::to_string(i), std::min(gc.emb_down, D + 1)});
+    for (int i = D; i >= 0; --i) blocks.push_back({"up_" + std::to_string(i), std::min(i, gc.emb_down)});
+    h->level_groups.clear();
+    for (int level = 0; level <= gc.emb_down; ++level) {
+      int col = 0;
+      for (auto& bl : blocks) {
+        if (bl.second != level) continue;
+        for (const char* which : {"0", "1"}) {
+          auto it = h->conv_index.find(bl.first + ".conv_block_" + which);
+          if (it == h->conv_index.end()) continue;
+          const ConvDef& c = h->convs[it->second];
+          if (!c.used || !c.spade_cond) continue;
+          SpadeGroup sg;
+          sg.C = c.cin; sg.Cp = h->padc(c.cin); sg.cond = c.spade_cond;
+          sg.nsets = (which[0] == '0' && h->conv_index.count(bl.first + ".conv_block_s")) ? 2 : 1;
+          sg.key = bl.first + "." + which;
+          sg.npad = (sg.nsets * sg.Cp + 31) / 32 * 64;
+          sg.level = level; sg.col0 = col; col += sg.npad;
+          sg.w_off = take((size_t)sg.npad * h->padc(sg.cond));      // (a multiple of 64 floats: no gap between two groups)
+          h->level_groups[level].push_back((int)h->spades.size());
+          h->spade_index[sg.key] = (int)h->spades.size();
+          h->spades.push_back(sg);
+        }
+      }
+    }
+    for (auto& sg : h->spades) sg.b_off = take(sg.npad);
   }
   for (auto& c : h->convs) { c.wu_off = 0; c.wu4_off = 0; c.zero_off = 0; }
   if (h->prec() == PREC_F32 && !getenv("RIB_NO_WINO")) {
@@ -689,6 +715,21 @@ struct Builder {
     ps->affine = affine; ps->g_off = g_off; ps->be_off = be_off;
     out->pend = ps;
   }
+  // A light consumer (k_wino_in, k_spade_modulate, k_in_add: channel slices of 64) reduces the producer's partials itself:
+  // fills the StatSrc scalars and the op's PRefs from the pending finalize of n, which then never launches unless another
+  // consumer needs the arrays.  false: the partials are gone / too many / the launch is forced -> the caller materializes.
+  bool take_partials(const Norm& n, StatSrc& st, Op& op, int slot) {
+    if (!has_partials(n) || n.pend->tiles > STATS_MAX_PARTIALS) return false;
+    const PendingStats& ps = *n.pend;
+    memset(&st, 0, sizeof st);
+    st.tiles = ps.tiles; st.Cs = ps.Cs; st.inv_count = ps.inv_count;
+    op.st_part[slot] = WS(ps.part_off);
+    if (ps.affine) { op.st_gamma[slot] = WT(ps.g_off); op.st_beta[slot] = WT(ps.be_off); }
+    return true;
+  }
+  // gamma/beta slab of a condition level (cond_level_gemm): [B][H*W][ld] fp32, group columns at SpadeGroup::col0
+  struct LevelSlab { size_t off = 0; int ld = 0; };
+  std::map<int, LevelSlab> level_slab;
   int tuneB = 0;      // batch whose tuned choices / cost-model decisions this plan follows (0: its own).  The labels-only
                       // plan of a chain follows the frame plan's, so that its results are bit-identical to per-frame launches
   int TB_() const { return tuneB > 0 ? tuneB : B; }
@@ -970,13 +1011,15 @@ struct Builder {
       op.wi.H = a.in.H; op.wi.W = a.in.W; op.wi.xC = a.in.Cp; op.wi.Cin = c.cinp; op.wi.tilesY = tilesY; op.wi.tilesX = tilesX;
       op.wi.pro_lrelu = a.pro_lrelu ? 1 : 0;
       op.wi_x = WS(a.in.off); op.wi_v = WS(v_off);
-      if (a.pro) {
+      if (a.pro && !(a.pro_choff == 0 && take_partials(*a.pro, op.wi.st, op, 0))) {
         materialize(*a.pro, gname);
         op.wi.pro_ld = a.pro->ld;
         op.wi_sc = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.wi_sh = WS(a.pro->sh + a.pro_choff * sizeof(float));
       }
-      const size_t total = (size_t)ntiles * (c.cinp / 4) * (wm + 2);      // thread = (tile, 4 channels, transformed row)
-      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192), B, 1);
+      // workgroup = (16 (tile, transformed row) units per pass) x (slice of 64 channels)
+      const int nsl = (c.cinp + 63) / 64, units = ntiles * (wm + 2);
+      op.wi.nslices = nsl; op.wi.ublocks = std::max(1, std::min((units + 15) / 16, 4096 / nsl));
+      op.grid = dim3(op.wi.ublocks * nsl, B, 1);
       push(op);
     }
     {   // the 16 / 36 GEMMs as one 1x1 "convolution" of NP*B samples of a tilesY x tilesX image, one filter set per position
@@ -1007,10 +1050,11 @@ struct Builder {
     {   // output transform + the convolution's epilogue
       Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_CONVAUX; op.name = opname + ".wino_out"; op.for_op = gname; op.wino_m = wm;
       memset(&op.wo, 0, sizeof op.wo);
-      // thread = (tile, output row, 4 channels): F(2x2) 128 / (coutp/4) tiles per block, F(4x4) 256 / (coutp/4) (tile, row) units
-      const int slots = 128 / (c.coutp / 4);
-      const int blocks = wm == 2 ? (ntiles + slots - 1) / slots : (ntiles * 4 + 2 * slots - 1) / (2 * slots);
-      op.wo.tilesY = tilesY; op.wo.tilesX = tilesX; op.wo.CoutPad = c.coutp; op.wo.blocks = blocks;
+      // workgroup = (16 (tile, output row) units per pass) x (slice of 64 channels); ONE statistics partial per unit block,
+      // at most STATS_MAX_PARTIALS of them, so the consumer of the normalised tensor can reduce them itself
+      const int nsl = (c.coutp + 63) / 64, units = ntiles * wm;
+      const int blocks = std::max(1, std::min((units + 15) / 16, (int)STATS_MAX_PARTIALS));
+      op.wo.tilesY = tilesY; op.wo.tilesX = tilesX; op.wo.CoutPad = c.coutp; op.wo.ublocks = blocks; op.wo.nslices = nsl;
       op.wo.yC = a.out.Cp; op.wo.yoff = a.yoff; op.wo.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
       op.wo.Hout = Hout; op.wo.Wout = Wout; op.wo.act = a.act;
       if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
@@ -1018,7 +1062,7 @@ struct Builder {
       if (a.res) { op.wo_res = WS(a.res->off); op.wo.resC = a.res->Cp; }
       size_t part_off = 0;
       if (a.want_stats) { part_off = alloc((size_t)B * blocks * 2 * c.coutp * sizeof(double)); op.wo_stat = WS(part_off); }
-      op.grid = dim3(blocks, B, 1);
+      op.grid = dim3(blocks * nsl, B, 1);
       push(op);
       if (a.want_stats) {
         Op f; f.kind = OP_FINALIZE; f.kclass = RIB_KC_STATS; f.name = opname + ".stats";
@@ -1033,6 +1077,56 @@ struct Builder {
         finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, blocks, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
       }
     }
+    return true;
+  }
+
+  // ---- gamma/beta of EVERY SPADE of a condition level in one 1x1 GEMM (round 3) -----------------------------------------
+  // The gamma/beta of a SPADE depend only on the condition map.  On the small deep maps (<= 64x64 at 512x512, batch 1) each
+  // SPADE's own GEMM is a 10-30 us launch of which 10-13 us are ramp and drain, and the ten of them
+  // that ran unfused were ten such launches.  The filter matrices of a level's SPADE groups lie back to back in the blob,
+  // so ONE k_igemm 1x1 launch on cond[level] with N = sum of their columns (8192 at level 4, 2048 at level 3 of HSM.yaml:
+  // 8.6 GFLOP each) writes a slab [B][H*W][N] and every SPADE of the level is then only its k_spade_modulate on its own
+  // column range.  Levels whose map is larger stay fused (gamma/beta never touch memory there).
+  bool cond_level_gemm(int level, const Act& cond) {
+    static const long max_px = getenv("RIB_COND_GEMM_MAX_PX") ? atol(getenv("RIB_COND_GEMM_MAX_PX")) : 4096;   // 0: off
+    const auto it = h->level_groups.find(level);
+    if (it == h->level_groups.end() || it->second.size() < 2 || (long)B * cond.H * cond.W > max_px) return true;
+    int N = 0; double fl = 0.0;
+    for (int gi : it->second) {
+      const SpadeGroup& sg = h->spades[gi];
+      if (sg.col0 != N || h->padc(sg.cond) != cond.Cp) { error = fmt("cond level %d: SPADE group %s does not continue the level's filter matrix", level, sg.key.c_str()); return false; }
+      N += sg.npad;
+      fl += 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)cond.H * cond.W * B;
+    }
+    const SpadeGroup& first = h->spades[it->second[0]];
+    const std::string name = fmt("cond_%d.gammabeta", level);
+    Choice ch = choose_variant(h->prec(), 1, 1, false, false, N, B, cond.H, cond.W, cond.Cp, false);
+    {
+      auto ct = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, name.c_str()));
+      if (ct != h->choices.end()) {
+        const Variant& tv = kVariants[ct->second.first];
+        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || tv.SPADE || tv.NF == 0 || cond.Cp % tv.BK != 0 || ct->second.second != 1) {
+          error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this launch", name.c_str(), ct->second.first, ct->second.second); return false;
+        }
+        ch.v = &tv; ch.ksplit = 1;
+      }
+    }
+    const Variant* v = ch.v;
+    if (!v) { error = name + ": no 1x1 kernel variant"; return false; }
+    const size_t slab_off = alloc((size_t)B * cond.H * cond.W * N * sizeof(float));
+    Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = name; op.var = v;
+    IgemmParams& p = op.ip;
+    memset(&p, 0, sizeof p);
+    p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
+    p.CoutPad = N; p.Hout = cond.H; p.Wout = cond.W; p.ksplit = 1;
+    p.tilesX = (cond.W + v->TW() - 1) / v->TW(); p.tilesY = (cond.H + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+    op.x = WS(cond.off); op.w = WT(h->mc16() ? first.w16_off : first.w_off); op.bias = WT(first.b_off); op.slab = WS(slab_off);
+    op.grid = dim3(p.tilesX * p.tilesY, (N + v->BN() - 1) / v->BN(), B);
+    op.flops = fl;
+    P->flops[RIB_KC_SPADE] += fl;
+    push(op);
+    LevelSlab ls; ls.off = slab_off; ls.ld = N;
+    level_slab[level] = ls;
     return true;
   }
 
@@ -1070,33 +1164,49 @@ struct Builder {
         else { uf.v = &tv; uf.ksplit = ts; unfused = true; }
       }
     }
+    // the level's gamma/beta GEMM already ran (cond_level_gemm): this SPADE is only its modulate
+    const auto lvl = level_slab.find(sg.level);
+    const bool from_level = lvl != level_slab.end();
+    if (from_level) unfused = true;
     if (!unfused && !v) { error = "no SPADE variant"; return false; }
     if (unfused) {
-      materialize(nx, key + ".spade");
       *ys0 = act(sg.C, Hout, Wout);
       if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
-      const Variant* cv = uf.v; const int S = uf.ksplit;
-      const size_t slab_off = alloc((size_t)S * B * Hout * Wout * sg.npad * sizeof(float));
-      Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = cv;
-      IgemmParams& p = op.ip;
-      memset(&p, 0, sizeof p);
-      p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
-      p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
-      p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
-      op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
-      op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
-      op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
-      P->flops[RIB_KC_SPADE] += op.flops;
-      push(op);
+      int S = 1, slab_ld = 0, col0 = 0;
+      size_t slab_off = 0;
+      if (from_level) {
+        slab_off = lvl->second.off; slab_ld = lvl->second.ld; col0 = sg.col0;
+      } else {
+        const Variant* cv = uf.v; S = uf.ksplit;
+        slab_off = alloc((size_t)S * B * Hout * Wout * sg.npad * sizeof(float)); slab_ld = sg.npad;
+        Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = key + ".spade"; op.var = cv;
+        IgemmParams& p = op.ip;
+        memset(&p, 0, sizeof p);
+        p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
+        p.CoutPad = sg.npad; p.Hout = Hout; p.Wout = Wout; p.ksplit = S;
+        p.tilesX = (Wout + cv->TW() - 1) / cv->TW(); p.tilesY = (Hout + cv->TH() - 1) / cv->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
+        op.x = WS(cond.off); op.w = WT(h->mc16() ? sg.w16_off : sg.w_off); op.bias = WT(sg.b_off); op.slab = WS(slab_off);
+        op.grid = dim3(p.tilesX * p.tilesY, (sg.npad + cv->BN() - 1) / cv->BN(), B * S);
+        op.flops = 2.0 * sg.cond * 2.0 * sg.nsets * sg.C * (double)Hout * Wout * B;
+        P->flops[RIB_KC_SPADE] += op.flops;
+        push(op);
+      }
       Op mo; mo.kind = OP_MODULATE; mo.kclass = RIB_KC_ELTWISE; mo.name = key + ".spade.modulate";
       memset(&mo.mp, 0, sizeof mo.mp);
-      mo.mp.ksplit = S; mo.mp.B = B; mo.mp.npad = sg.npad; mo.mp.xmC = x.Cp; mo.mp.xm_ups = x_ups ? 1 : 0;
+      mo.mp.ksplit = S; mo.mp.B = B; mo.mp.slab_ld = slab_ld; mo.mp.col0 = col0; mo.mp.xmC = x.Cp; mo.mp.xm_ups = x_ups ? 1 : 0;
       mo.mp.m_ld = nx.ld; mo.mp.C = sg.Cp; mo.mp.nsets = sg.nsets; mo.mp.act0 = act0 ? ACT_LRELU : ACT_NONE; mo.mp.act1 = ACT_NONE;
       mo.mp.Hout = Hout; mo.mp.Wout = Wout;
-      mo.m_slab = WS(slab_off); mo.m_bias = WT(sg.b_off); mo.m_xm = WS(x.off); mo.m_sc = WS(nx.sc); mo.m_sh = WS(nx.sh);
+      mo.m_slab = WS(slab_off); mo.m_bias = WT(sg.b_off); mo.m_xm = WS(x.off);
+      // a slice of 64 virtual channels lies inside one set when C is a multiple of 64: the modulate can then reduce the
+      // producer's partials of its own channels
+      if (!(sg.Cp % 64 == 0 && nx.pend && !nx.pend->affine && sg.Cp <= nx.pend->Cs && take_partials(nx, mo.mp.st, mo, 0))) {
+        materialize(nx, key + ".spade");
+        mo.m_sc = WS(nx.sc); mo.m_sh = WS(nx.sh);
+      }
       mo.m_ys0 = WS(ys0->off); if (sg.nsets == 2) mo.m_ys1 = WS(ys1->off);
-      const size_t total = (size_t)Hout * Wout * (sg.nsets * sg.Cp / 4);
-      mo.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), B, 1);
+      const int nsl = (sg.nsets * sg.Cp + 63) / 64;
+      mo.mp.nslices = nsl; mo.mp.pblocks = std::max(1, std::min((Hout * Wout + 15) / 16, 2048 / nsl));
+      mo.grid = dim3(mo.mp.pblocks * nsl, B, 1);
       push(mo);
       return true;
     }
@@ -1202,7 +1312,7 @@ struct Builder {
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
                    &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst,
                    &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat,
-                   &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat};
+                   &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat, &op.st_part[0], &op.st_part[1]};
     for (PRef* r : all) if (r->sp == PS_WS) f(*r);
   }
   AllocRec* alloc_of(size_t voff) {
@@ -1348,6 +1458,9 @@ struct Builder {
         tap("cond_" + std::to_string(i + 1), cond[i + 1]);
       }
     }
+    // gamma/beta of all SPADEs of the small condition levels, one GEMM per level (cond_level_gemm)
+    for (int j = 0; j <= c.emb_down; ++j)
+      if (!cond_level_gemm(j, cond[j])) return false;
 
     // ---- label branch of the mask network (depends only on the label map) ----
     const std::string m = "flow_network_temp";
@@ -1448,17 +1561,19 @@ struct Builder {
         if (!conv(a, cs.name)) return false;
       } else if (first) { error = "mask res block 0 must have a learned shortcut"; return false; }
       Act o = act(c1.cout, Hm, Wm);
-      materialize(n1);
-      if (learned) materialize(ns);
       Op op; op.kind = OP_INADD; op.kclass = RIB_KC_ELTWISE; op.name = bn + ".join";
       memset(&op.ap, 0, sizeof op.ap);
       op.ap.C = o.Cp; op.ap.HW = Hm * Wm; op.ap.ld = n1.ld;
-      op.a_t1 = WS(t1.off); op.a_sc1 = WS(n1.sc); op.a_sh1 = WS(n1.sh);
-      if (learned) { op.a_ts = WS(ts.off); op.a_scs = WS(ns.sc); op.a_shs = WS(ns.sh); }
-      else op.a_x = WS(xin.off);
+      op.a_t1 = WS(t1.off);
+      if (!take_partials(n1, op.ap.st1, op, 0)) { materialize(n1); op.a_sc1 = WS(n1.sc); op.a_sh1 = WS(n1.sh); }
+      if (learned) {
+        op.a_ts = WS(ts.off);
+        if (!take_partials(ns, op.ap.sts, op, 1)) { materialize(ns); op.a_scs = WS(ns.sc); op.a_shs = WS(ns.sh); }
+      } else op.a_x = WS(xin.off);
       op.a_out = WS(o.off);
-      const size_t total = (size_t)Hm * Wm * (o.Cp / 4);
-      op.grid = dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048), B, 1);
+      const int nsl = (o.Cp + 63) / 64;
+      op.ap.nslices = nsl; op.ap.pblocks = std::max(1, std::min((Hm * Wm + 15) / 16, 2048 / nsl));
+      op.grid = dim3(op.ap.pblocks * nsl, B, 1);
       push(op);
       tap("mask.res_" + std::to_string(i), o);
       r = o; first = false;
@@ -1587,6 +1702,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         ModulateParams p = op.mp;
         p.slab = R.get<const float>(op.m_slab); p.bias = R.get<const float>(op.m_bias); p.xm = R.get<const float>(op.m_xm);
         p.m_scale = R.get<const float>(op.m_sc); p.m_shift = R.get<const float>(op.m_sh);
+        p.st.part = R.get<const double>(op.st_part[0]); p.st.gamma = R.get<const float>(op.st_gamma[0]); p.st.beta = R.get<const float>(op.st_beta[0]);
         p.ys0 = R.get<float>(op.m_ys0); p.ys1 = R.get<float>(op.m_ys1);
         if (bf16) hipLaunchKernelGGL(k_spade_modulate<true>, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_spade_modulate<false>, op.grid, dim3(256), 0, st, p);
@@ -1609,6 +1725,8 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.t1 = R.get<const float>(op.a_t1); p.sc1 = R.get<const float>(op.a_sc1); p.sh1 = R.get<const float>(op.a_sh1);
         p.ts = R.get<const float>(op.a_ts); p.scs = R.get<const float>(op.a_scs); p.shs = R.get<const float>(op.a_shs);
         p.xres = R.get<const float>(op.a_x); p.out = R.get<float>(op.a_out);
+        p.st1.part = R.get<const double>(op.st_part[0]); p.st1.gamma = R.get<const float>(op.st_gamma[0]); p.st1.beta = R.get<const float>(op.st_beta[0]);
+        p.sts.part = R.get<const double>(op.st_part[1]); p.sts.gamma = R.get<const float>(op.st_gamma[1]); p.sts.beta = R.get<const float>(op.st_beta[1]);
         if (bf16) hipLaunchKernelGGL(k_in_add<true>, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_in_add<false>, op.grid, dim3(256), 0, st, p);
       } break;
@@ -1616,6 +1734,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         WinoInParams p = op.wi;
         p.x = R.get<const float>(op.wi_x); p.pro_scale = R.get<const float>(op.wi_sc); p.pro_shift = R.get<const float>(op.wi_sh);
         p.v = R.get<float>(op.wi_v);
+        p.st.part = R.get<const double>(op.st_part[0]); p.st.gamma = R.get<const float>(op.st_gamma[0]); p.st.beta = R.get<const float>(op.st_beta[0]);
         if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_in, op.grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_wino_in, op.grid, dim3(256), 0, st, p);
       } break;
