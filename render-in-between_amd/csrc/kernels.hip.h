@@ -159,6 +159,12 @@ struct IgemmParams {
   // --- batched GEMM with one filter set per "sample" (the 16 Winograd positions: k_wino_in / k_wino_out): sample n
   // reads the filters at w + (n % w_mod) * w_stride elements; w_mod = 0: one filter set for all samples ---
   int w_mod; unsigned w_stride;
+  // --- two convolutions of identical shape in ONE launch (round 3: level i of the mask network's label encoder and of its
+  // image encoder, PGNR/models/generator.py:449-459): samples come in pairs, sample 2b + j is image b of convolution j;
+  // w_mod = 2 picks the filters, b_stride (floats) the bias.  pair != 0: the two results of a pair land in ONE output
+  // image, y[b] at channel offsets yoff and yoff + pair_yoff (the torch.cat of generator.py:505); the statistics partials
+  // stay per sample ---
+  unsigned b_stride; int pair, pair_yoff;
 };
 
 enum { STATS_MAX_PARTIALS = 128 };
@@ -939,6 +945,9 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
     // per fragment cost 4 more registers in the NF = 2 variants, i.e. 4 -> 3 waves per SIMD (96 + 32 -> 99 + 32)
     double* red = reinterpret_cast<double*>(smem);   // [WM][BN][2]
     if (p.stat_part) __syncthreads();                // all waves finished the main loop: smem can be reused
+    const float* pbias = p.bias + (p.w_mod ? (size_t)(n % p.w_mod) * p.b_stride : 0);
+    const int ny = p.pair ? (n >> 1) : n;            // output image and channel offset of this sample
+    const int yoff = p.pair ? p.yoff + (n & 1) * p.pair_yoff : p.yoff;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       // sum(x), sum(x^2) of this lane's valid elements without cancellation at fp32 cost: deviations from a pivot (the
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       float pv = 0.f, d1 = 0.f, d2 = 0.f;
       const int col = n0 + (wn * NF + nf) * 32 + li;
       const bool cvalid = col < p.Cout;
-      const float bv = (col < p.CoutPad) ? p.bias[col] : 0.f;
+      const float bv = (col < p.CoutPad) ? pbias[col] : 0.f;
 #pragma unroll
       for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
           int ox = tx0 + row % FRW;
           if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
           if (okm & (1u << r)) {
-            const size_t yi = (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.yC + p.yoff + col;
+            const size_t yi = (((size_t)ny * p.Hout + oy) * p.Wout + ox) * p.yC + yoff + col;
             if constexpr (BF16) { if (p.y_f32) p.y[yi] = vv[r]; else st_act<true>(p.y, yi, vv[r]); }
             else p.y[yi] = vv[r];
           }
@@ -1199,6 +1208,10 @@ struct FinalizeParams {
   int ld, off;
   float inv_count;     // 1 / (H*W)
   float eps;
+  // paired producer (IgemmParams::pair): sample n belongs to convolution n & 1, whose IN affine lies g_stride floats behind
+  // the first one's; pair_merge: the two rows of a pair go into ONE row n >> 1 of the arrays, at channel offsets off and
+  // off + pair_off (the concatenated tensor's statistics)
+  int g_stride, pair_merge, pair_off;
 };
 
 __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p) {
@@ -1227,11 +1240,13 @@ __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p)
     double var = s2 * (double)p.inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    const float g = p.gamma ? p.gamma[c] : 1.f;
-    const float b = p.beta ? p.beta[c] : 0.f;
+    const int gs = (n & 1) * p.g_stride;
+    const float g = p.gamma ? p.gamma[gs + c] : 1.f;
+    const float b = p.beta ? p.beta[gs + c] : 0.f;
     const float sc = rstd * g;
-    p.scale[(size_t)n * p.ld + p.off + c] = sc;
-    p.shift[(size_t)n * p.ld + p.off + c] = b - (float)mean * sc;
+    const size_t at = p.pair_merge ? (size_t)(n >> 1) * p.ld + p.off + (n & 1) * p.pair_off + c : (size_t)n * p.ld + p.off + c;
+    p.scale[at] = sc;
+    p.shift[at] = b - (float)mean * sc;
   }
 }
 
@@ -1787,26 +1802,38 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
   const float4 bb = *reinterpret_cast<const float4*>(p.bias + colg + 32);
   const int act = set ? p.act1 : p.act0;
   float* yout = set ? p.ys1 : p.ys0;
-  for (int pix = pb * 16 + (threadIdx.x >> 4); pix < npix; pix += p.pblocks * 16) {
-    const float* src = p.slab + ((size_t)n * npix + pix) * p.slab_ld + p.col0 + colg;
-    float4 g = *reinterpret_cast<const float4*>(src);
-    float4 b = *reinterpret_cast<const float4*>(src + 32);
-#pragma unroll 4
-    for (int s = 1; s < p.ksplit; ++s) {
-      const float4 g2 = *reinterpret_cast<const float4*>(src + s * sstride);
-      const float4 b2 = *reinterpret_cast<const float4*>(src + s * sstride + 32);
-      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
-      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+  // four pixels per iteration: all loads (clamped addresses) first, then the arithmetic and the stores - a load behind a
+  // store of the previous pixel would wait for that store ("reading the ISA")
+  const int pstep = p.pblocks * 16;
+  for (int pix0 = pb * 16 + (threadIdx.x >> 4); pix0 < npix; pix0 += 4 * pstep) {
+    float4 g[4], b[4], x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = min(pix0 + k * pstep, npix - 1);
+      const float* src = p.slab + ((size_t)n * npix + pix) * p.slab_ld + p.col0 + colg;
+      g[k] = *reinterpret_cast<const float4*>(src);
+      b[k] = *reinterpret_cast<const float4*>(src + 32);
+      for (int s = 1; s < p.ksplit; ++s) {
+        const float4 g2 = *reinterpret_cast<const float4*>(src + s * sstride);
+        const float4 b2 = *reinterpret_cast<const float4*>(src + s * sstride + 32);
+        g[k].x += g2.x; g[k].y += g2.y; g[k].z += g2.z; g[k].w += g2.w;
+        b[k].x += b2.x; b[k].y += b2.y; b[k].z += b2.z; b[k].w += b2.w;
+      }
+      const int oy = pix / p.Wout, ox = pix % p.Wout;
+      const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+      x[k] = ld_act4<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
     }
-    const int oy = pix / p.Wout, ox = pix % p.Wout;
-    const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-    const float4 x = ld_act4<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
-    float4 o;
-    o.x = apply_act((x.x * sc.x + sh.x) * (1.f + (g.x + bg.x)) + (b.x + bb.x), act);
-    o.y = apply_act((x.y * sc.y + sh.y) * (1.f + (g.y + bg.y)) + (b.y + bb.y), act);
-    o.z = apply_act((x.z * sc.z + sh.z) * (1.f + (g.z + bg.z)) + (b.z + bb.z), act);
-    o.w = apply_act((x.w * sc.w + sh.w) * (1.f + (g.w + bg.w)) + (b.w + bb.w), act);
-    st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = pix0 + k * pstep;
+      if (pix >= npix) break;
+      float4 o;
+      o.x = apply_act((x[k].x * sc.x + sh.x) * (1.f + (g[k].x + bg.x)) + (b[k].x + bb.x), act);
+      o.y = apply_act((x[k].y * sc.y + sh.y) * (1.f + (g[k].y + bg.y)) + (b[k].y + bb.y), act);
+      o.z = apply_act((x[k].z * sc.z + sh.z) * (1.f + (g[k].z + bg.z)) + (b[k].z + bb.z), act);
+      o.w = apply_act((x[k].w * sc.w + sh.w) * (1.f + (g[k].w + bg.w)) + (b[k].w + bb.w), act);
+      st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
+    }
   }
 }
 
@@ -1912,18 +1939,26 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
     if (p.sts.part) { s2 = make_float4(s_sc[1][l], s_sc[1][l + 1], s_sc[1][l + 2], s_sc[1][l + 3]); t2 = make_float4(s_sh[1][l], s_sh[1][l + 1], s_sh[1][l + 2], s_sh[1][l + 3]); }
     else { s2 = *reinterpret_cast<const float4*>(p.scs + (size_t)n * p.ld + c4 * 4); t2 = *reinterpret_cast<const float4*>(p.shs + (size_t)n * p.ld + c4 * 4); }
   }
-  for (int pix = pb * 16 + (threadIdx.x >> 4); pix < p.HW; pix += p.pblocks * 16) {
-    const size_t e = ((size_t)n * p.HW + pix) * p.C + c4 * 4;
-    const float4 a = ld_act4<BF16>(p.t1, e);
-    float4 o = make_float4(a.x * s.x + t.x, a.y * s.y + t.y, a.z * s.z + t.z, a.w * s.w + t.w);
-    if (p.ts) {
-      const float4 b = ld_act4<BF16>(p.ts, e);
-      o.x += b.x * s2.x + t2.x; o.y += b.y * s2.y + t2.y; o.z += b.z * s2.z + t2.z; o.w += b.w * s2.w + t2.w;
-    } else {
-      const float4 b = ld_act4<BF16>(p.xres, e);
-      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+  const float* second = p.ts ? p.ts : p.xres;
+  if (!p.ts) { s2 = make_float4(1.f, 1.f, 1.f, 1.f); t2 = make_float4(0.f, 0.f, 0.f, 0.f); }     // + xres
+  const int pstep = p.pblocks * 16;
+  for (int pix0 = pb * 16 + (threadIdx.x >> 4); pix0 < p.HW; pix0 += 4 * pstep) {   // four pixels per iteration, loads first
+    float4 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t e = ((size_t)n * p.HW + min(pix0 + k * pstep, p.HW - 1)) * p.C + c4 * 4;
+      a[k] = ld_act4<BF16>(p.t1, e);
+      b[k] = ld_act4<BF16>(second, e);
     }
-    st_act4<BF16>(p.out, e, o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pix = pix0 + k * pstep;
+      if (pix >= p.HW) break;
+      float4 o = make_float4(a[k].x * s.x + t.x, a[k].y * s.y + t.y, a[k].z * s.z + t.z, a[k].w * s.w + t.w);
+      if (p.ts) { o.x += b[k].x * s2.x + t2.x; o.y += b[k].y * s2.y + t2.y; o.z += b[k].z * s2.z + t2.z; o.w += b[k].w * s2.w + t2.w; }
+      else { o.x += b[k].x; o.y += b[k].y; o.z += b[k].z; o.w += b[k].w; }
+      st_act4<BF16>(p.out, ((size_t)n * p.HW + pix) * p.C + c4 * 4, o);
+    }
   }
 }
 

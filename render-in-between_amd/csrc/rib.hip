@@ -699,6 +699,7 @@ struct Builder {
   size_t ws = 0;
   std::string error;
   bool mark_label = false;
+  bool pair_mask = false;    // the two encoders of the mask network level by level in paired launches (mask_branches_paired)
   bool defer_stats = true;   // false: every k_stats_finalize launch is emitted where its producer is (labels-only plans)
   // a consumer needs the (scale, shift) ARRAYS of n: emit the finalize launch now if it is still pending
   void materialize(const Norm& n, const std::string& consumer = std::string()) {
@@ -754,11 +755,16 @@ struct Builder {
     a.off = alloc((size_t)B * H * W * a.Cp * h->esz());
     return a;
   }
-  Norm norm(int Cp) {
+  Norm norm(int Cp, int images = 0) {
     Norm n; n.ld = Cp; n.valid = true;
-    n.sc = alloc((size_t)B * Cp * sizeof(float));
-    n.sh = alloc((size_t)B * Cp * sizeof(float));
+    n.sc = alloc((size_t)(images ? images : B) * Cp * sizeof(float));
+    n.sh = alloc((size_t)(images ? images : B) * Cp * sizeof(float));
     return n;
+  }
+  Act act_n(int images, int C, int H, int W) {     // an activation of `images` images instead of B
+    Act a; a.C = C; a.Cp = h->padc(C); a.H = H; a.W = W;
+    a.off = alloc((size_t)images * H * W * a.Cp * h->esz());
+    return a;
   }
   // an activation that is never materialised: up to three of the caller's NCHW tensors, concatenated along channels
   Act virt(int C, int H, int W, int s0, int c0, int s1 = 0, int c1 = 0, int s2 = 0, int c2 = 0) {
@@ -802,6 +808,12 @@ struct Builder {
     Norm* stats_out = nullptr; size_t stats_choff = 0;  // finalize target (+channel offset)
     bool affine = false;    // finalize with the conv's IN gamma/beta
     bool stats_now = false; // emit the finalize launch at the producer (the arrays are shared / copied between plans)
+    // Two convolutions of identical shape in one launch (IgemmParams::pair): `pair` is the second one; `in` / `out` hold
+    // 2B images (image 2b + j belongs to convolution j).  pair_merge: the outputs of a pair land in ONE image of `out`
+    // (B images) at channel offsets yoff and yoff + pair_yoff, and their statistics in one row of stats_out.
+    const ConvDef* pair = nullptr; bool pair_merge = false; int pair_yoff = 0;
+    bool no_split = false;              // never grid-level split-K (the paired launch cannot, and its unpaired twins must match it)
+    std::vector<std::string> choice_names;   // tuned-choice keys tried before the op's own name
   };
 
   bool conv(const ConvArgs& a, const std::string& opname) {
@@ -809,6 +821,15 @@ struct Builder {
     const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
     const int Wout = a.ups ? a.in.W * 2 : (c.stride == 2 ? a.in.W / 2 : a.in.W);
     if (a.in.virt) return conv_lowc(a, opname);
+    const int nB = a.pair ? 2 * B : B;       // images in `in`
+    if (a.pair) {
+      const ConvDef& d = *a.pair;
+      if (d.cinp != c.cinp || d.coutp != c.coutp || d.cout != c.cout || d.ks != c.ks || d.stride != c.stride || d.ups_in || c.ups_in || a.ups || a.res || a.aux ||
+          a.y_nchw.sp != PS_NULL || a.y_user.sp != PS_NULL || a.y_none || !a.want_stats || c.in_affine != d.in_affine || d.w_off <= c.w_off || d.b_off <= c.b_off ||
+          (c.in_affine && (d.g_off <= c.g_off || d.g_off - c.g_off != d.be_off - c.be_off)) || (h->mc16() && d.w16_off <= c.w16_off)) {
+        error = opname + ": the two convolutions of a paired launch must have the same shape"; return false;
+      }
+    }
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
     {
       // Winograd F(2x2, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h)
@@ -821,12 +842,17 @@ struct Builder {
     }
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
-    const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !getenv("RIB_NO_SPLITK");
+    const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !a.pair && !a.no_split && !getenv("RIB_NO_SPLITK");
     // the 16-column path serves layers with <= 16 output channels and no residual read
     const bool can_n16 = c.cout <= 16 && !a.res && !h->mc16() && !getenv("RIB_NO_N16");
     Choice ch = choose_variant(h->prec(), c.stride, c.ks, a.ups, false, c.coutp, TB_(), Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
-      auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, opname.c_str()));
+      auto it = h->choices.end();
+      for (const std::string& nm : a.choice_names) {
+        it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, nm.c_str()));
+        if (it != h->choices.end()) break;
+      }
+      if (it == h->choices.end()) it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, opname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
@@ -884,6 +910,13 @@ struct Builder {
       p.Cout = a.cout_store >= 0 ? a.cout_store : h->padc(c.cout);
       if (a.out.H != Hout || a.out.W != Wout) { error = fmt("%s: output size mismatch", opname.c_str()); return false; }
     }
+    if (a.pair) {
+      const bool w16p = h->mc16();
+      p.w_mod = 2;
+      p.w_stride = (unsigned)(w16p ? 2 * (a.pair->w16_off - c.w16_off) : a.pair->w_off - c.w_off);      // elements of the filter's storage type
+      p.b_stride = (unsigned)(a.pair->b_off - c.b_off);
+      p.pair = a.pair_merge ? 1 : 0; p.pair_yoff = a.pair_yoff;
+    }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
     if (a.y_none && !(small && c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV") && a.y_nchw.sp != PS_NULL)) {
@@ -905,11 +938,12 @@ struct Builder {
     }
     int tiles = p.tilesX * p.tilesY;
     size_t part_off = 0;
-    op.grid = dim3(tiles, v->NF == 0 ? 1 : (c.coutp + v->BN() - 1) / v->BN(), B * S);
-    op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * B + aux_flops;
+    op.grid = dim3(tiles, v->NF == 0 ? 1 : (c.coutp + v->BN() - 1) / v->BN(), nB * S);
+    op.flops = 2.0 * c.cin * c.ks * c.ks * c.cout * (double)Hout * Wout * nB + aux_flops;
     P->flops[RIB_KC_IGEMM] += op.flops;
+    if (a.pair && (S != 1 || v->NF == 0)) { error = opname + ": a paired launch cannot split K or use the 16-column path"; return false; }
     if (S == 1) {
-      if (a.want_stats) { part_off = alloc((size_t)B * tiles * 2 * c.coutp * sizeof(double)); op.stat = WS(part_off); }
+      if (a.want_stats) { part_off = alloc((size_t)nB * tiles * 2 * c.coutp * sizeof(double)); op.stat = WS(part_off); }
       push(op);
     } else {
       // split-K: the conv writes raw partial slabs; a second kernel sums them and runs the epilogue
@@ -939,10 +973,11 @@ struct Builder {
       f.f_part = WS(part_off);
       if (a.affine) { f.f_gamma = WT(c.g_off); f.f_beta = WT(c.be_off); }
       f.f_scale = WS(a.stats_out->sc); f.f_shift = WS(a.stats_out->sh);
-      f.grid = dim3(c.coutp / 16, B, 1);
+      f.grid = dim3(c.coutp / 16, nB, 1);
+      if (a.pair) { f.fp.g_stride = a.affine ? (int)(a.pair->g_off - c.g_off) : 0; f.fp.pair_merge = a.pair_merge ? 1 : 0; f.fp.pair_off = a.pair_yoff; }
       // (a channel offset means two producers share the arrays - the concatenated encoders of the mask network -
-      // and consumers would need two partial sources: those keep their launch)
-      finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
+      // and consumers would need two partial sources: those keep their launch; so does a paired launch)
+      finalize_or_defer(f, a.stats_out, a.stats_choff != 0 || a.stats_now || a.pair != nullptr, part_off, tiles, c.coutp, f.fp.inv_count, a.affine, c.g_off, c.be_off);
     }
     return true;
   }
@@ -1018,7 +1053,8 @@ struct Builder {
       }
       // workgroup = (16 (tile, transformed row) units per pass) x (slice of 64 channels)
       const int nsl = (c.cinp + 63) / 64, units = ntiles * (wm + 2);
-      op.wi.nslices = nsl; op.wi.ublocks = std::max(1, std::min((units + 15) / 16, 4096 / nsl));
+      // (every workgroup that reduces partials re-reads tiles x 64 channels x 16 bytes: few, fatter workgroups then)
+      op.wi.nslices = nsl; op.wi.ublocks = std::max(1, std::min((units + 15) / 16, (op.wi.st.tiles > 0 ? 512 : 4096) / nsl));
       op.grid = dim3(op.wi.ublocks * nsl, B, 1);
       push(op);
     }
@@ -1205,7 +1241,7 @@ struct Builder {
       }
       mo.m_ys0 = WS(ys0->off); if (sg.nsets == 2) mo.m_ys1 = WS(ys1->off);
       const int nsl = (sg.nsets * sg.Cp + 63) / 64;
-      mo.mp.nslices = nsl; mo.mp.pblocks = std::max(1, std::min((Hout * Wout + 15) / 16, 2048 / nsl));
+      mo.mp.nslices = nsl; mo.mp.pblocks = std::max(1, std::min((Hout * Wout + 15) / 16, (mo.mp.st.tiles > 0 ? 384 : 2048) / nsl));
       mo.grid = dim3(mo.mp.pblocks * nsl, B, 1);
       push(mo);
       return true;
@@ -1294,6 +1330,10 @@ struct Builder {
       Norm no = lastl ? ncat : norm(h->padc(cd.cout));
       ConvArgs a; a.cd = &cd; a.in = cur; a.out = o;
       if (have) { a.pro = &ncur; a.pro_lrelu = true; }
+      if (i >= 1) {      // same kernel choice as the paired launch of this level (mask_branches_paired): bit-identical results
+        a.no_split = true;
+        a.choice_names = {m + ".down_pair." + std::to_string(i), m + ".down_img." + std::to_string(i)};
+      }
       // the last level's (scale, shift) land in the shared arrays of the concatenated tensor: its finalize is emitted at
       // the producer (`no` is a local copy of ncat: a deferred finalize attached to it would be lost)
       if (lastl) { a.yoff = b * chm; a.stats_choff = (size_t)b * chm; a.stats_now = true; }
@@ -1301,6 +1341,52 @@ struct Builder {
       if (!conv(a, cd.name)) return false;
       if (!lastl) tap(std::string("mask.") + (b == 0 ? "lbl_" : "img_") + std::to_string(i) + ".raw", o);
       cur = o; ncur = no; have = true;
+    }
+    return true;
+  }
+
+  // Both stride-2 encoders of the mask network, level by level (round 3): level i >= 1 of the label encoder and of the image
+  // encoder are the same convolution on different tensors with different filters (32 -> 64 -> 128 -> 256 channels at
+  // HSM.yaml's widths, 2.4 GFLOP each), ~35 us launches that cannot fill the chip one at a time: ONE launch computes both
+  // (IgemmParams::pair).  Level 0 reads different inputs (22 / 9 channels): two launches into the two halves of a 2-image
+  // buffer.  Batch 1 only; a chain keeps the encoders apart (its label encoder runs once per segment at batch T).
+  bool mask_branches_paired(const Act& L, const Act& I9, const Act& CAT, const Norm& ncat, int chm) {
+    const rib_config& c = h->g.c;
+    const std::string m = "flow_network_temp";
+    const Act* inputs[2] = {&L, &I9};
+    const char* branches[2] = {"down_lbl", "down_img"};
+    Act cur; Norm ncur;
+    {
+      const ConvDef& c0 = conv_of(h, m + ".down_lbl.0");
+      cur = act_n(2, c0.cout, L.H, L.W); ncur = norm(h->padc(c0.cout), 2);
+      const size_t img_bytes = (size_t)L.H * L.W * cur.Cp * h->esz();
+      for (int b = 0; b < 2; ++b) {
+        const ConvDef& cd = conv_of(h, m + "." + branches[b] + ".0");
+        Act o = cur; o.off += b * img_bytes;                                   // image b of the pair buffer
+        Norm no = ncur; no.sc += (size_t)b * ncur.ld * sizeof(float); no.sh += (size_t)b * ncur.ld * sizeof(float);
+        ConvArgs a; a.cd = &cd; a.in = *inputs[b]; a.out = o; a.want_stats = true; a.stats_out = &no; a.affine = true; a.stats_now = true;
+        if (!conv(a, cd.name)) return false;
+        tap(std::string("mask.") + (b == 0 ? "lbl_0" : "img_0") + ".raw", o);
+      }
+    }
+    for (int i = 1; i <= c.mask_down; ++i) {
+      const ConvDef& cl = conv_of(h, m + ".down_lbl." + std::to_string(i));
+      const ConvDef& ci = conv_of(h, m + ".down_img." + std::to_string(i));
+      const bool lastl = (i == c.mask_down);
+      Act o = lastl ? CAT : act_n(2, cl.cout, cur.H / 2, cur.W / 2);
+      Norm no = lastl ? ncat : norm(h->padc(cl.cout), 2);
+      ConvArgs a; a.cd = &cl; a.pair = &ci; a.in = cur; a.out = o; a.pro = &ncur; a.pro_lrelu = true;
+      if (lastl) { a.pair_merge = true; a.pair_yoff = chm; }
+      a.want_stats = true; a.stats_out = &no; a.affine = true; a.no_split = true;
+      a.choice_names = {m + ".down_pair." + std::to_string(i), m + ".down_img." + std::to_string(i)};
+      if (!conv(a, m + ".down_pair." + std::to_string(i))) return false;
+      if (!lastl) {
+        const size_t img_bytes = (size_t)o.H * o.W * o.Cp * h->esz();
+        Act ol = o, oi = o; oi.off += img_bytes;
+        tap("mask.lbl_" + std::to_string(i) + ".raw", ol);
+        tap("mask.img_" + std::to_string(i) + ".raw", oi);
+      }
+      cur = o; ncur = no;
     }
     return true;
   }
@@ -1469,9 +1555,11 @@ struct Builder {
     if (h->padc(chm) != chm) { error = "mask network width must be a multiple of 8 (16 with bf16 storage)"; return false; }
     Act CAT = act(2 * chm, Hm, Wm);
     Norm ncat = norm(CAT.Cp);
-    mark_label = true;
-    if (!mask_branch(0, L, CAT, ncat, chm)) return false;
-    mark_label = false;
+    if (!pair_mask) {
+      mark_label = true;
+      if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+      mark_label = false;
+    }
 
     // ---- main generator (generator.py:201-228) ----
     Act x; Norm nx;
@@ -1535,7 +1623,7 @@ struct Builder {
     }
 
     // ---- MaskGenerator (generator.py:493-510): image branch, then join with the label branch ----
-    if (!mask_branch(1, I9, CAT, ncat, chm)) return false;
+    if (pair_mask ? !mask_branches_paired(L, I9, CAT, ncat, chm) : !mask_branch(1, I9, CAT, ncat, chm)) return false;
     tap("mask.cat.raw", CAT);
     Act r; bool first = true;
     for (int i = 0; i < c.mask_res_blocks; ++i) {
@@ -1572,7 +1660,7 @@ struct Builder {
       } else op.a_x = WS(xin.off);
       op.a_out = WS(o.off);
       const int nsl = (o.Cp + 63) / 64;
-      op.ap.nslices = nsl; op.ap.pblocks = std::max(1, std::min((Hm * Wm + 15) / 16, 2048 / nsl));
+      op.ap.nslices = nsl; op.ap.pblocks = std::max(1, std::min((Hm * Wm + 15) / 16, ((op.ap.st1.tiles > 0 || op.ap.sts.tiles > 0) ? 384 : 2048) / nsl));
       op.grid = dim3(op.ap.pblocks * nsl, B, 1);
       push(op);
       tap("mask.res_" + std::to_string(i), o);
@@ -1599,8 +1687,18 @@ struct Builder {
   }
 };
 
-Plan* get_plan(rib_handle* h, int B, int H, int W, bool labels_only = false, int tuneB = 0) {
-  const uint64_t key = ((uint64_t)(labels_only ? 1 : 0) << 63) | ((uint64_t)(tuneB & 0x7f) << 56) | ((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W;
+// PLAN_LABELS: the label-only launches alone (rib_chain's batched pre-pass).  PLAN_UNPAIRED: a frame plan that keeps the mask
+// network's label encoder in launches of its own (rib_chain skips them); the default frame plan pairs the two encoders
+// level by level at batch 1 (Builder::mask_branches_paired) - same kernels, same choices, bit-identical frames.
+enum { PLAN_LABELS = 1, PLAN_UNPAIRED = 2 };
+inline bool plan_pairs(int B, int flags) {
+  static const bool off = getenv("RIB_NO_PAIR") != nullptr;
+  return !off && B == 1 && !(flags & (PLAN_LABELS | PLAN_UNPAIRED));
+}
+Plan* get_plan(rib_handle* h, int B, int H, int W, int flags = 0, int tuneB = 0) {
+  const bool labels_only = (flags & PLAN_LABELS) != 0;
+  if (!labels_only && !plan_pairs(B, 0)) flags &= ~PLAN_UNPAIRED;      // one frame plan where nothing is paired anyway
+  const uint64_t key = ((uint64_t)(flags & 3) << 62) | ((uint64_t)(tuneB & 0x3f) << 56) | ((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W;
   auto it = h->plans.find(key);
   if (it != h->plans.end()) return it->second.get();
   const int mult = 1 << std::max(h->g.c.num_down_img, h->g.c.mask_down);
@@ -1618,7 +1716,7 @@ Plan* get_plan(rib_handle* h, int B, int H, int W, bool labels_only = false, int
   }
   std::unique_ptr<Plan> P(new Plan());
   P->B = B; P->H = H; P->W = W;
-  Builder b; b.h = h; b.P = P.get(); b.B = B; b.tuneB = tuneB;
+  Builder b; b.h = h; b.P = P.get(); b.B = B; b.tuneB = tuneB; b.pair_mask = plan_pairs(B, flags);
   if (!(labels_only ? b.build_labels() : b.build())) { h->err = "plan: " + b.error; return nullptr; }
   Plan* raw = P.get();
   h->plans[key] = std::move(P);
@@ -2092,8 +2190,14 @@ size_t rib_workspace_bytes(rib_handle* h, int B, int H, int W) {
   if (!h) return 0;
   Plan* P = get_plan(h, B, H, W);
   if (!P) return 0;
+  size_t need = P->ws_bytes;
+  if (plan_pairs(B, 0)) {      // rib_chain runs the unpaired twin of the frame plan on the same workspace
+    Plan* PU = get_plan(h, B, H, W, PLAN_UNPAIRED);
+    if (!PU) return 0;
+    need = std::max(need, PU->ws_bytes);
+  }
   // + scratch img/mask frames rib_chain uses when the caller does not ask for them
-  return P->ws_bytes + 2 * align256((size_t)B * h->g.c.image_nc * H * W * sizeof(float)) +
+  return need + 2 * align256((size_t)B * h->g.c.image_nc * H * W * sizeof(float)) +
          align256((size_t)B * H * W * sizeof(float));
 }
 
@@ -2240,7 +2344,7 @@ size_t rib_chain_workspace_bytes(rib_handle* h, int T, int B, int H, int W) {
   if (!h || T < 1) return 0;
   const size_t base = rib_workspace_bytes(h, B, H, W);
   if (base == 0 || !chain_batches_labels(h, T, B)) return base;
-  Plan* PL = get_plan(h, T * B, H, W, true, B);
+  Plan* PL = get_plan(h, T * B, H, W, PLAN_LABELS, B);
   return PL ? base + align256(PL->ws_bytes) : 0;
 }
 
@@ -2250,7 +2354,9 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
   int rc = check_ready(h);
   if (rc) return rc;
   if (T < 1 || !key_frame || !labels || !dains || !fuses || !workspace) return fail(h, RIB_ERR_INVALID, "rib_chain: bad argument");
-  Plan* P = get_plan(h, B, H, W);
+  // a chain that runs the label-only launches once per segment needs them apart from the image encoder's: the unpaired
+  // twin of the frame plan (same kernels and choices: the frames equal rib_forward's bit for bit)
+  Plan* P = get_plan(h, B, H, W, chain_batches_labels(h, T, B) ? PLAN_UNPAIRED : 0);
   if (!P) return RIB_ERR_INVALID;
   const rib_config& c = h->g.c;
   const size_t frame = (size_t)B * c.image_nc * H * W, mframe = (size_t)B * H * W, lframe = (size_t)B * c.label_nc * H * W;
@@ -2267,7 +2373,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
   Plan* PL = nullptr;
   char* lws = nullptr;
   if (chain_batches_labels(h, T, B)) {
-    PL = get_plan(h, T * B, H, W, true, B);
+    PL = get_plan(h, T * B, H, W, PLAN_LABELS, B);
     if (!PL) return RIB_ERR_INVALID;
     const size_t off = align256(need);
     if (workspace_bytes >= off + PL->ws_bytes) {
@@ -2438,11 +2544,13 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
     if (variant_idx >= kNumVariants || ksplit < 1) return fail(h, RIB_ERR_INVALID, "rib_set_choice: bad variant / ksplit");
     h->choices[key] = {variant_idx, ksplit};
   }
-  h->plans.erase(((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W);   // rebuilt on next use
-  // ... and the labels-only plans of chains that follow this shape's choices (key: labels bit, tuneB, T*B, H, W)
+  // the frame plans of this shape (paired and unpaired) are rebuilt on next use, and so are the labels-only plans of
+  // chains that follow this shape's choices (key: flags [63:62], tuneB [61:56], batch [55:40], H [39:20], W [19:0])
   for (auto it = h->plans.begin(); it != h->plans.end();) {
     const uint64_t k = it->first;
-    const bool follows = (k >> 63) && (int)((k >> 56) & 0x7f) == B && (int)((k >> 20) & 0xfffff) == H && (int)(k & 0xfffff) == W;
+    const bool labels = ((k >> 62) & PLAN_LABELS) != 0;
+    const bool same_hw = (int)((k >> 20) & 0xfffff) == H && (int)(k & 0xfffff) == W;
+    const bool follows = same_hw && (labels ? (int)((k >> 56) & 0x3f) == B : (int)((k >> 40) & 0xffff) == B);
     if (follows) it = h->plans.erase(it); else ++it;
   }
   return RIB_OK;
