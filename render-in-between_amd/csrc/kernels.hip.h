@@ -1420,37 +1420,113 @@ __device__ __forceinline__ void block_stats_64(const StatSrc& s, int n, int c0, 
 // units per pass; blockIdx.x = unit block * nslices + slice.  The output transforms emit ONE statistics partial per unit
 // block (<= 64 of them), so that the consumer of the normalised tensor can reduce them itself (block_stats_64).
 // ---------------------------------------------------------------------------------------------
+enum { WSRC_PLAIN = 0, WSRC_SPADE = 1, WSRC_JOIN = 2 };
 struct WinoInParams {
   const float* x; int H, W, xC, Cin;        // input activation [B][H][W][xC], Cin channels used (multiple of 4)
   const float* pro_scale; const float* pro_shift; int pro_ld, pro_lrelu;   // optional prologue (as k_igemm's)
   StatSrc st;                                // consumer-side finalize: replaces pro_scale / pro_shift when st.part != nullptr
   float* v; int tilesY, tilesX;
   int nslices, ublocks;                      // grid.x = ublocks * nslices (channel slices of 64)
+  // WSRC_SPADE: the input is the output of an unfused SPADE that is never stored (round 3): x is the tensor being
+  // normalised (at half resolution when x_ups), (scale, shift) its InstanceNorm, gamma/beta come from the condition level's
+  // slab (k_spade_modulate's arithmetic, spade_mod1), then LeakyReLU when pro_lrelu
+  int x_ups; const float* slab; int slab_ld, col0; const float* sbias;
+  // WSRC_JOIN: the input is the mask network's residual join (k_in_add's arithmetic), out = IN(x) + (x2 ? IN2(x2) : xres),
+  // which the unit that owns a pixel also stores to o (the next join's residual); no activation
+  const float* x2; const float* xres; float* o; const float* pro2_scale; const float* pro2_shift; StatSrc st2;
 };
 
-// prologue constants of this thread's four channels: from the workgroup's own reduction, from the arrays, or identity
-__device__ __forceinline__ void wino_in_prologue(const WinoInParams& p, int n, int slice, int c4, bool cok, double* red, float* s_sc,
-                                                 float* s_sh, float4& sc, float4& sh, bool& aff) {
-  sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  aff = false;
+// out = IN(x) * (1 + gamma) + beta with the roundings pinned (two fused multiply-adds), shared by k_spade_modulate and the
+// Winograd input transforms that apply the modulation on the fly: bit-identical either way
+__device__ __forceinline__ float spade_mod1(float x, float sc, float sh, float g, float bg, float b, float bb) {
+  return fmaf(fmaf(x, sc, sh), 1.f + (g + bg), b + bb);
+}
+
+template <int MODE> struct WinoConsts { float4 sc, sh, bg, bb, sc2, sh2; bool aff; };
+template <int MODE> struct WinoRaw { float4 a, b, c; };
+
+// per-thread constants of a Winograd input transform: (scale, shift) of this thread's four channels from the workgroup's
+// own reduction, from the arrays, or identity; SPADE: the gamma/beta bias; JOIN: the second tensor's (scale, shift)
+template <int MODE>
+__device__ __forceinline__ void wino_in_consts(const WinoInParams& p, int n, int slice, int c4, bool cok, double* red, float* s_sc,
+                                               float* s_sh, WinoConsts<MODE>& k) {
+  k.sc = make_float4(1.f, 1.f, 1.f, 1.f); k.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  k.aff = false;
+  const int l = (threadIdx.x & 15) * 4;
   if (p.st.part) {
     block_stats_64(p.st, n, slice * 64, min(64, p.Cin - slice * 64), red, s_sc, s_sh);
-    const int l = (threadIdx.x & 15) * 4;
-    sc = make_float4(s_sc[l], s_sc[l + 1], s_sc[l + 2], s_sc[l + 3]);
-    sh = make_float4(s_sh[l], s_sh[l + 1], s_sh[l + 2], s_sh[l + 3]);
-    aff = true;
+    k.sc = make_float4(s_sc[l], s_sc[l + 1], s_sc[l + 2], s_sc[l + 3]);
+    k.sh = make_float4(s_sh[l], s_sh[l + 1], s_sh[l + 2], s_sh[l + 3]);
+    k.aff = true;
   } else if (p.pro_scale && cok) {
-    sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
-    sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
-    aff = true;
+    k.sc = *reinterpret_cast<const float4*>(p.pro_scale + (size_t)n * p.pro_ld + c4 * 4);
+    k.sh = *reinterpret_cast<const float4*>(p.pro_shift + (size_t)n * p.pro_ld + c4 * 4);
+    k.aff = true;
   }
+  if constexpr (MODE == WSRC_SPADE) {
+    const int v = c4 * 4, colg = (v / 32) * 64 + (v % 32);
+    k.bg = cok ? *reinterpret_cast<const float4*>(p.sbias + colg) : k.sh;
+    k.bb = cok ? *reinterpret_cast<const float4*>(p.sbias + colg + 32) : k.sh;
+  }
+  if constexpr (MODE == WSRC_JOIN) {
+    k.sc2 = make_float4(1.f, 1.f, 1.f, 1.f); k.sh2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.x2) {
+      if (p.st2.part) {
+        __syncthreads();                       // s_sc / s_sh of the first tensor have been read by every thread
+        block_stats_64(p.st2, n, slice * 64, min(64, p.Cin - slice * 64), red, s_sc, s_sh);
+        k.sc2 = make_float4(s_sc[l], s_sc[l + 1], s_sc[l + 2], s_sc[l + 3]);
+        k.sh2 = make_float4(s_sh[l], s_sh[l + 1], s_sh[l + 2], s_sh[l + 3]);
+      } else if (cok) {
+        k.sc2 = *reinterpret_cast<const float4*>(p.pro2_scale + (size_t)n * p.pro_ld + c4 * 4);
+        k.sh2 = *reinterpret_cast<const float4*>(p.pro2_shift + (size_t)n * p.pro_ld + c4 * 4);
+      }
+    }
+  }
+}
+
+// the loads of one input element (clamped coordinates cy, cx: always valid addresses)
+template <int MODE>
+__device__ __forceinline__ void wino_fetch(const WinoInParams& p, int n, int cy, int cx, int c4, WinoRaw<MODE>& r) {
+  if constexpr (MODE == WSRC_SPADE) {
+    const int Hs = p.x_ups ? p.H >> 1 : p.H, Ws = p.x_ups ? p.W >> 1 : p.W;
+    const int sy = p.x_ups ? cy >> 1 : cy, sx = p.x_ups ? cx >> 1 : cx;
+    r.a = *reinterpret_cast<const float4*>(p.x + (((size_t)n * Hs + sy) * Ws + sx) * p.xC + c4 * 4);
+    const int v = c4 * 4, colg = (v / 32) * 64 + (v % 32);
+    const float* sl = p.slab + (((size_t)n * p.H + cy) * p.W + cx) * p.slab_ld + p.col0 + colg;
+    r.b = *reinterpret_cast<const float4*>(sl);
+    r.c = *reinterpret_cast<const float4*>(sl + 32);
+  } else {
+    const size_t e = (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4;
+    r.a = *reinterpret_cast<const float4*>(p.x + e);
+    if constexpr (MODE == WSRC_JOIN) r.b = *reinterpret_cast<const float4*>((p.x2 ? p.x2 : p.xres) + e);
+  }
+}
+
+// the value the convolution sees at an in-image element (zero padding is the caller's)
+template <int MODE>
+__device__ __forceinline__ float4 wino_value(const WinoInParams& p, const WinoConsts<MODE>& k, const WinoRaw<MODE>& r) {
+  float4 w = r.a;
+  if constexpr (MODE == WSRC_SPADE) {
+    w = make_float4(spade_mod1(r.a.x, k.sc.x, k.sh.x, r.b.x, k.bg.x, r.c.x, k.bb.x), spade_mod1(r.a.y, k.sc.y, k.sh.y, r.b.y, k.bg.y, r.c.y, k.bb.y),
+                    spade_mod1(r.a.z, k.sc.z, k.sh.z, r.b.z, k.bg.z, r.c.z, k.bb.z), spade_mod1(r.a.w, k.sc.w, k.sh.w, r.b.w, k.bg.w, r.c.w, k.bb.w));
+    if (p.pro_lrelu) w = lrelu4(w);
+  } else if constexpr (MODE == WSRC_JOIN) {
+    w = make_float4(w.x * k.sc.x + k.sh.x, w.y * k.sc.y + k.sh.y, w.z * k.sc.z + k.sh.z, w.w * k.sc.w + k.sh.w);
+    if (p.x2) { w.x += r.b.x * k.sc2.x + k.sh2.x; w.y += r.b.y * k.sc2.y + k.sh2.y; w.z += r.b.z * k.sc2.z + k.sh2.z; w.w += r.b.w * k.sc2.w + k.sh2.w; }
+    else { w.x += r.b.x; w.y += r.b.y; w.z += r.b.z; w.w += r.b.w; }
+  } else {
+    if (k.aff) w = make_float4(w.x * k.sc.x + k.sh.x, w.y * k.sc.y + k.sh.y, w.z * k.sc.z + k.sh.z, w.w * k.sc.w + k.sh.w);
+    if (p.pro_lrelu) w = lrelu4(w);
+  }
+  return w;
 }
 
 #define RIB_F4_SUB(a, b) make_float4((a).x - (b).x, (a).y - (b).y, (a).z - (b).z, (a).w - (b).w)
 #define RIB_F4_ADD(a, b) make_float4((a).x + (b).x, (a).y + (b).y, (a).z + (b).z, (a).w + (b).w)
 
+template <int MODE>
 __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
-  // thread = ((tile, row r of the transformed tile), 4 channels of the slice): a row needs two input rows (8 loads)
+  // thread = ((tile, row r of the transformed tile), 4 channels of the slice): a row needs two input rows (8 elements)
   __shared__ double red[4 * 64 * 2];
   __shared__ float s_sc[64], s_sh[64];
   const int c4n = p.Cin / 4;
@@ -1459,8 +1535,8 @@ __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
   const int c4 = slice * 16 + (threadIdx.x & 15);
   const bool cok = c4 < c4n;
   const int ntiles = p.tilesY * p.tilesX;
-  float4 sc, sh; bool aff;
-  wino_in_prologue(p, n, slice, c4, cok, red, s_sc, s_sh, sc, sh, aff);
+  WinoConsts<MODE> kc;
+  wino_in_consts<MODE>(p, n, slice, c4, cok, red, s_sc, s_sh, kc);
   if (!cok) return;
   for (int u = ub * 16 + (threadIdx.x >> 4); u < ntiles * 4; u += p.ublocks * 16) {
     const int r = u & 3, tile = u >> 2;
@@ -1468,14 +1544,13 @@ __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
     // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: row r of B^T d is d[ia] + sg * d[ib]
     const int ia = r == 0 ? 0 : (r == 2 ? 2 : 1), ib = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
     const float sg = r == 1 ? 1.f : -1.f;
-    float4 d[2][4];
+    WinoRaw<MODE> d[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int iy = 2 * ty - 1 + (a ? ib : ia), ix = 2 * tx - 1 + q;
-        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        d[a][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
+        wino_fetch<MODE>(p, n, min(max(iy, 0), p.H - 1), min(max(ix, 0), p.W - 1), c4, d[a][q]);
       }
     float4 t[4];
 #pragma unroll
@@ -1484,10 +1559,12 @@ __global__ __launch_bounds__(256) void k_wino_in(const WinoInParams p) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int iy = 2 * ty - 1 + (a ? ib : ia), ix = 2 * tx - 1 + q;
-        float4 w = d[a][q];
-        if (aff) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
-        if (p.pro_lrelu) w = lrelu4(w);
-        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+        const bool inb = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        float4 w = wino_value<MODE>(p, kc, d[a][q]);
+        if constexpr (MODE == WSRC_JOIN) {      // row r = 1 reads the tile's own 2x2 pixels (rows 1, 2; columns 1, 2): it stores them
+          if (r == 1 && (q == 1 || q == 2) && inb) *reinterpret_cast<float4*>(p.o + (((size_t)n * p.H + iy) * p.W + ix) * p.xC + c4 * 4) = w;
+        }
+        if (!inb) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
         v[a] = w;
       }
       t[q] = make_float4(v[0].x + sg * v[1].x, v[0].y + sg * v[1].y, v[0].z + sg * v[1].z, v[0].w + sg * v[1].w);
@@ -1614,6 +1691,7 @@ __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc) {
 __device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
 
 // thread = ((tile, transformed row r), 4 channels of the slice); row r of B^T d needs the 3 or 4 input rows with a non-zero coefficient
+template <int MODE>
 __global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
   __shared__ double red[4 * 64 * 2];
   __shared__ float s_sc[64], s_sh[64];
@@ -1623,39 +1701,61 @@ __global__ __launch_bounds__(256) void k_wino4_in(const WinoInParams p) {
   const int c4 = slice * 16 + (threadIdx.x & 15);
   const bool cok = c4 < c4n;
   const int ntiles = p.tilesY * p.tilesX;
-  float4 sc, sh; bool aff;
-  wino_in_prologue(p, n, slice, c4, cok, red, s_sc, s_sh, sc, sh, aff);
+  WinoConsts<MODE> kc;
+  wino_in_consts<MODE>(p, n, slice, c4, cok, red, s_sc, s_sh, kc);
   if (!cok) return;
   for (int u = ub * 16 + (threadIdx.x >> 4); u < ntiles * 6; u += p.ublocks * 16) {
     const int r = u % 6, tile = u / 6;
     const int ty = tile / p.tilesX, tx = tile % p.tilesX;
     // rows with a non-zero coefficient: r = 0 -> {0, 2, 4}; r = 1..4 -> {1, 2, 3, 4}; r = 5 -> {1, 3, 5}
     const int a0 = r == 0 ? 0 : 1, da = (r == 0 || r == 5) ? 2 : 1, na = (r == 0 || r == 5) ? 3 : 4;
-    float4 d[4][6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int iy = 4 * ty - 1 + a0 + min(k, na - 1) * da, ix = 4 * tx - 1 + q;
-        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        d[k][q] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + cy) * p.W + cx) * p.xC + c4 * 4);
-      }
     float4 t[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) t[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == WSRC_PLAIN) {
+      // all 24 loads of the unit first (one memory round trip), then the arithmetic
+      WinoRaw<MODE> d[4][6];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int a = a0 + min(k, na - 1) * da;
-      const float coef = k < na ? kWino4BT[r][a] : 0.f;
-      const int iy = 4 * ty - 1 + a;
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int ix = 4 * tx - 1 + q;
-        float4 w = d[k][q];
-        if (aff) w = make_float4(w.x * sc.x + sh.x, w.y * sc.y + sh.y, w.z * sc.z + sh.z, w.w * sc.w + sh.w);
-        if (p.pro_lrelu) w = lrelu4(w);
-        if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
-        t[q] = f4_fma(coef, w, t[q]);
+        for (int q = 0; q < 6; ++q) {
+          const int iy = 4 * ty - 1 + a0 + min(k, na - 1) * da, ix = 4 * tx - 1 + q;
+          wino_fetch<MODE>(p, n, min(max(iy, 0), p.H - 1), min(max(ix, 0), p.W - 1), c4, d[k][q]);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int a = a0 + min(k, na - 1) * da;
+        const float coef = k < na ? kWino4BT[r][a] : 0.f;
+        const int iy = 4 * ty - 1 + a;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int ix = 4 * tx - 1 + q;
+          float4 w = wino_value<MODE>(p, kc, d[k][q]);
+          if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding after the prologue
+          t[q] = f4_fma(coef, w, t[q]);
+        }
+      }
+    } else {
+      // two or three loads per element: one input row at a time (6 elements in flight) to stay within the registers
+#pragma unroll 1
+      for (int k = 0; k < na; ++k) {
+        const int a = a0 + k * da;
+        const float coef = kWino4BT[r][a];
+        const int iy = 4 * ty - 1 + a;
+        WinoRaw<MODE> d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wino_fetch<MODE>(p, n, min(max(iy, 0), p.H - 1), min(max(4 * tx - 1 + q, 0), p.W - 1), c4, d[q]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int ix = 4 * tx - 1 + q;
+          const bool inb = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          float4 w = wino_value<MODE>(p, kc, d[q]);
+          if constexpr (MODE == WSRC_JOIN) {    // row r = 1 reads the tile's own 4x4 pixels (rows 1..4; columns 1..4): it stores them
+            if (r == 1 && q >= 1 && q <= 4 && inb) *reinterpret_cast<float4*>(p.o + (((size_t)n * p.H + iy) * p.W + ix) * p.xC + c4 * 4) = w;
+          }
+          if (!inb) w = make_float4(0.f, 0.f, 0.f, 0.f);
+          t[q] = f4_fma(coef, w, t[q]);
+        }
       }
     }
     const size_t plane = (size_t)ntiles * p.Cin;
@@ -1828,10 +1928,10 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
       const int pix = pix0 + k * pstep;
       if (pix >= npix) break;
       float4 o;
-      o.x = apply_act((x[k].x * sc.x + sh.x) * (1.f + (g[k].x + bg.x)) + (b[k].x + bb.x), act);
-      o.y = apply_act((x[k].y * sc.y + sh.y) * (1.f + (g[k].y + bg.y)) + (b[k].y + bb.y), act);
-      o.z = apply_act((x[k].z * sc.z + sh.z) * (1.f + (g[k].z + bg.z)) + (b[k].z + bb.z), act);
-      o.w = apply_act((x[k].w * sc.w + sh.w) * (1.f + (g[k].w + bg.w)) + (b[k].w + bb.w), act);
+      o.x = apply_act(spade_mod1(x[k].x, sc.x, sh.x, g[k].x, bg.x, b[k].x, bb.x), act);
+      o.y = apply_act(spade_mod1(x[k].y, sc.y, sh.y, g[k].y, bg.y, b[k].y, bb.y), act);
+      o.z = apply_act(spade_mod1(x[k].z, sc.z, sh.z, g[k].z, bg.z, b[k].z, bb.z), act);
+      o.w = apply_act(spade_mod1(x[k].w, sc.w, sh.w, g[k].w, bg.w, b[k].w, bb.w), act);
       st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
     }
   }

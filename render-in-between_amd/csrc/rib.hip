@@ -405,7 +405,7 @@ struct Op {
   PackParams kp; PRef k_s0, k_s1, k_s2, k_dst;
   LowcParams lc; PRef lc_s0, lc_s1, lc_s2, lc_w, lc_bias, lc_y, lc_stat; int lowc_ce = 0, lowc_ncol = 0, lowc_tw = 32;
   // Winograd transforms
-  WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v;
+  WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v, wi_slab, wi_sbias, wi_x2, wi_xres, wi_o, wi_sc2, wi_sh2; int wi_mode = 0;
   WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
   bool wino = false;   // this k_igemm launch is the 16- / 36-way batched Winograd-domain GEMM (executes 4/9 or 1/4 of its nine-tap FLOP count)
   int wino_m = 0;      // 2 or 4 on the three launches of a Winograd convolution
@@ -420,12 +420,16 @@ struct PendingStats {
 
 struct Tap { std::string name; size_t off; int Cp, C, H, W; };
 
+struct LazySrc;
 struct Act {       // NHWC activation in the workspace
   size_t off = 0;  // bytes
   int Cp = 0, C = 0, H = 0, W = 0;
   // virt: never materialised - the channel concatenation of up to three of the caller's NCHW fp32 tensors, read in place
   // by k_conv_lowc (usrc: user slots, uc: their channel counts)
   bool virt = false; int usrc[3] = {0, 0, 0}, uc[3] = {0, 0, 0};
+  // lazy: never stored - the output of an unfused SPADE (WSRC_SPADE) or of a mask-network join (WSRC_JOIN) that the
+  // Winograd input transform of its only consumer computes on the fly (Builder::conv_wino)
+  std::shared_ptr<LazySrc> lazy;
 };
 struct PendingStats;
 struct Norm {      // (scale, shift) arrays [B][ld]
@@ -435,6 +439,15 @@ struct Norm {      // (scale, shift) arrays [B][ld]
   // producer's partial sums itself (k_igemm prologue / SPADE epilogue, few partials) takes them from here and the
   // launch never happens; any other consumer emits it first (Builder::materialize)
   std::shared_ptr<PendingStats> pend;
+};
+
+struct LazySrc {
+  int mode = 0;                 // WSRC_SPADE / WSRC_JOIN
+  std::string name;             // the launch this replaces (for error messages)
+  Act x; Norm nx;               // SPADE: tensor being normalised + its statistics; JOIN: t1 + n1
+  bool x_ups = false, lrelu = false;
+  size_t slab_off = 0; int slab_ld = 0, col0 = 0; size_t sbias_off = 0;      // SPADE: gamma/beta slab of the level, this group's bias
+  bool has2 = false; Act x2; Norm n2; Act xres; Act o;                         // JOIN: ts + ns (learned shortcut) or xres; o = the stored join
 };
 
 // results of the label-only launches, as (offset, bytes) into the plan's workspace: in an autoregressive chain the
@@ -816,6 +829,18 @@ struct Builder {
     std::vector<std::string> choice_names;   // tuned-choice keys tried before the op's own name
   };
 
+  // Winograd F(2x2, 3x3) / F(4x4, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h):
+  // maps up to 128x128 (1024x1024 frames: +3.5 % at batch 1 and 4); beyond that V and M (4x the activation each)
+  // leave the caches and the direct kernel, which fills the chip there, was not beaten
+  bool runs_wino(const ConvArgs& a, int Hout, int Wout) const {
+    static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
+    const ConvDef& c = *a.cd;
+    return h->prec() == PREC_F32 && (c.wu_off || c.wu4_off) && !a.ups && !a.aux && !a.res_ups && !a.pair && !a.in.virt && a.y_nchw.sp == PS_NULL &&
+           a.y_user.sp == PS_NULL && (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2;
+  }
+  // would conv `cd` on an HxW map (stride 1, plain arguments) run in the Winograd domain?  (callers that want to hand it a lazy input)
+  bool would_wino(const ConvDef& cd, int H, int W) const { ConvArgs t; t.cd = &cd; return runs_wino(t, H, W); }
+
   bool conv(const ConvArgs& a, const std::string& opname) {
     const ConvDef& c = *a.cd;
     const int Hout = a.ups ? a.in.H * 2 : (c.stride == 2 ? a.in.H / 2 : a.in.H);
@@ -831,15 +856,8 @@ struct Builder {
       }
     }
     if (a.in.Cp != c.cinp) { error = fmt("%s: input channels %d != expected %d", opname.c_str(), a.in.Cp, c.cinp); return false; }
-    {
-      // Winograd F(2x2, 3x3) on the small maps (k_wino_in / batched 1x1 k_igemm / k_wino_out; kernels.hip.h)
-      // maps up to 128x128 (1024x1024 frames: +3.5 % at batch 1 and 4); beyond that V and M (4x the activation each)
-      // leave the caches and the direct kernel, which fills the chip there, was not beaten
-      static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
-      if (h->prec() == PREC_F32 && c.wu_off && !a.ups && !a.aux && !a.res_ups && a.y_nchw.sp == PS_NULL && a.y_user.sp == PS_NULL &&
-          (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2)
-        return conv_wino(a, opname, Hout, Wout);
-    }
+    if (runs_wino(a, Hout, Wout)) return conv_wino(a, opname, Hout, Wout);
+    if (a.in.lazy) { error = opname + ": a lazy input (" + a.in.lazy->name + ") needs the Winograd path"; return false; }
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
     const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !a.pair && !a.no_split && !getenv("RIB_NO_SPLITK");
@@ -1046,7 +1064,25 @@ struct Builder {
       op.wi.H = a.in.H; op.wi.W = a.in.W; op.wi.xC = a.in.Cp; op.wi.Cin = c.cinp; op.wi.tilesY = tilesY; op.wi.tilesX = tilesX;
       op.wi.pro_lrelu = a.pro_lrelu ? 1 : 0;
       op.wi_x = WS(a.in.off); op.wi_v = WS(v_off);
-      if (a.pro && !(a.pro_choff == 0 && take_partials(*a.pro, op.wi.st, op, 0))) {
+      if (a.in.lazy) {
+        const LazySrc& L = *a.in.lazy;
+        if (a.pro || a.pro_lrelu) { error = gname + ": a lazy input carries its own prologue"; return false; }
+        op.wi_mode = L.mode;
+        op.wi_x = WS(L.x.off); op.wi.xC = L.x.Cp;
+        op.wi.pro_ld = L.nx.ld;
+        if (!take_partials(L.nx, op.wi.st, op, 0)) { materialize(L.nx, gname); op.wi_sc = WS(L.nx.sc); op.wi_sh = WS(L.nx.sh); }
+        if (L.mode == WSRC_SPADE) {
+          op.wi.x_ups = L.x_ups ? 1 : 0; op.wi.pro_lrelu = L.lrelu ? 1 : 0;
+          op.wi_slab = WS(L.slab_off); op.wi.slab_ld = L.slab_ld; op.wi.col0 = L.col0; op.wi_sbias = WT(L.sbias_off);
+        } else {
+          if (L.has2) {
+            op.wi_x2 = WS(L.x2.off);
+            if (L.n2.ld != L.nx.ld) { error = gname + ": join operands with different statistics rows"; return false; }
+            if (!take_partials(L.n2, op.wi.st2, op, 1)) { materialize(L.n2, gname); op.wi_sc2 = WS(L.n2.sc); op.wi_sh2 = WS(L.n2.sh); }
+          } else op.wi_xres = WS(L.xres.off);
+          op.wi_o = WS(L.o.off);
+        }
+      } else if (a.pro && !(a.pro_choff == 0 && take_partials(*a.pro, op.wi.st, op, 0))) {
         materialize(*a.pro, gname);
         op.wi.pro_ld = a.pro->ld;
         op.wi_sc = WS(a.pro->sc + a.pro_choff * sizeof(float)); op.wi_sh = WS(a.pro->sh + a.pro_choff * sizeof(float));
@@ -1167,8 +1203,10 @@ struct Builder {
   }
 
   // ---- SPADE launch: ys0 (= lrelu(mod0(x))), optional ys1 (= mods(x), no activation) -------
+  // lazy_ok: the only consumer of ys0 is a convolution that runs in the Winograd domain - when this SPADE is just a modulate
+  // of the level's gamma/beta slab (one set), ys0 is not stored: the convolution's input transform computes it (LazySrc)
   bool spade(const std::string& key, const Act& cond, const Act& x, bool x_ups, const Norm& nx,
-             Act* ys0, Act* ys1, bool act0) {
+             Act* ys0, Act* ys1, bool act0, bool lazy_ok = false) {
     const SpadeGroup& sg = h->spades[h->spade_index.at(key)];
     const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
     if (cond.H != Hout || cond.W != Wout) { error = fmt("%s: cond map %dx%d != %dx%d (SPADE resize must be the identity)", key.c_str(), cond.H, cond.W, Hout, Wout); return false; }
@@ -1205,6 +1243,15 @@ struct Builder {
     const bool from_level = lvl != level_slab.end();
     if (from_level) unfused = true;
     if (!unfused && !v) { error = "no SPADE variant"; return false; }
+    static const bool no_lazy = getenv("RIB_NO_LAZY") != nullptr;
+    if (from_level && lazy_ok && sg.nsets == 1 && !h->keep_taps && !no_lazy && h->prec() == PREC_F32) {
+      auto L = std::make_shared<LazySrc>();
+      L->mode = WSRC_SPADE; L->name = key + ".spade.modulate"; L->x = x; L->nx = nx; L->x_ups = x_ups; L->lrelu = act0;
+      L->slab_off = lvl->second.off; L->slab_ld = lvl->second.ld; L->col0 = sg.col0; L->sbias_off = sg.b_off;
+      Act y; y.C = sg.C; y.Cp = sg.Cp; y.H = Hout; y.W = Wout; y.lazy = L;
+      *ys0 = y;
+      return true;
+    }
     if (unfused) {
       *ys0 = act(sg.C, Hout, Wout);
       if (sg.nsets == 2) *ys1 = act(sg.C, Hout, Wout);
@@ -1285,16 +1332,22 @@ struct Builder {
     const bool learned = h->conv_index.count(name + ".conv_block_s") > 0;
     const int Hout = x_ups ? x.H * 2 : x.H, Wout = x_ups ? x.W * 2 : x.W;
     Act ys0, ys1;
-    if (!spade(name + ".0", cond, x, x_ups, nx, &ys0, &ys1, true)) return false;
-    tap(name + ".ys0", ys0);
     Act hbuf = act(c0.cout, Hout, Wout);
     Norm nh = norm(hbuf.Cp);
-    { ConvArgs a; a.cd = &c0; a.in = ys0; a.out = hbuf; a.want_stats = true; a.stats_out = &nh;
+    { ConvArgs a; a.cd = &c0; a.out = hbuf; a.want_stats = true; a.stats_out = &nh;
+      if (!spade(name + ".0", cond, x, x_ups, nx, &ys0, &ys1, true, runs_wino(a, Hout, Wout))) return false;
+      if (!ys0.lazy) tap(name + ".ys0", ys0);
+      a.in = ys0;
       if (!conv(a, name + ".conv_block_0")) return false; }
     tap(name + ".h", hbuf);
     Act y1, dummy;
-    if (!spade(name + ".1", cond, hbuf, false, nh, &y1, &dummy, true)) return false;
-    tap(name + ".y1", y1);
+    {
+      // conv_block_1 runs in the Winograd domain only with an identity shortcut at the same resolution (the res blocks)
+      ConvArgs t; t.cd = &c1; t.res = &x; t.res_ups = !learned && x_ups;
+      const bool lazy1 = !learned && runs_wino(t, Hout, Wout);
+      if (!spade(name + ".1", cond, hbuf, false, nh, &y1, &dummy, true, lazy1)) return false;
+    }
+    if (!y1.lazy) tap(name + ".y1", y1);
     // learned shortcut (residual.py:98-108): its 1x1 convolution on SPADE_s(x) is fused into
     // conv_block_1's launch as extra K chunks accumulating into the same output tile
     const bool fuse_s = learned && !getenv("RIB_NO_FUSE_SHORTCUT");
@@ -1397,7 +1450,7 @@ struct Builder {
                    &op.s_slab, &op.s_bias, &op.s_y, &op.s_res, &op.s_stat, &op.m_slab, &op.m_bias, &op.m_xm, &op.m_sc, &op.m_sh,
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
                    &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst,
-                   &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat,
+                   &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wi_slab, &op.wi_x2, &op.wi_xres, &op.wi_o, &op.wi_sc2, &op.wi_sh2, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat,
                    &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat, &op.st_part[0], &op.st_part[1]};
     for (PRef* r : all) if (r->sp == PS_WS) f(*r);
   }
@@ -1631,7 +1684,8 @@ struct Builder {
       const ConvDef& c0 = conv_of(h, bn + ".conv_block_0");
       const ConvDef& c1 = conv_of(h, bn + ".conv_block_1");
       const bool learned = h->conv_index.count(bn + ".conv_block_s") > 0;
-      const Act& xin = first ? CAT : r;
+      const Act xin = first ? CAT : r;                              // (lazy: the previous block's join, computed by this block's first input transform)
+      const Act xin_stored = xin.lazy ? xin.lazy->o : xin;          // ... which also stores it: the residual of this block's join
       Act t0 = act(c0.cout, Hm, Wm); Norm n0 = norm(t0.Cp);
       { ConvArgs a; a.cd = &c0; a.in = xin; a.out = t0; if (first) { a.pro = &ncat; a.pro_lrelu = true; }
         a.want_stats = true; a.stats_out = &n0; a.affine = true;
@@ -1649,6 +1703,22 @@ struct Builder {
         if (!conv(a, cs.name)) return false;
       } else if (first) { error = "mask res block 0 must have a learned shortcut"; return false; }
       Act o = act(c1.cout, Hm, Wm);
+      {
+        // the join feeds the next block's conv_block_0 (no prologue): when that runs in the Winograd domain its input
+        // transform computes the join on the fly and stores it
+        static const bool no_lazy = getenv("RIB_NO_LAZY") != nullptr;
+        ConvArgs t;
+        if (i + 1 < c.mask_res_blocks) t.cd = &conv_of(h, m + ".res_flow." + std::to_string(i + 1) + ".conv_block_0");
+        if (t.cd && !no_lazy && h->prec() == PREC_F32 && runs_wino(t, Hm, Wm) && t.cd->cinp == o.Cp && n1.ld == o.Cp) {
+          auto L = std::make_shared<LazySrc>();
+          L->mode = WSRC_JOIN; L->name = bn + ".join"; L->x = t1; L->nx = n1; L->o = o;
+          if (learned) { L->has2 = true; L->x2 = ts; L->n2 = ns; } else L->xres = xin_stored;
+          Act y = o; y.lazy = L;
+          tap("mask.res_" + std::to_string(i), o);
+          r = y; first = false;
+          continue;
+        }
+      }
       Op op; op.kind = OP_INADD; op.kclass = RIB_KC_ELTWISE; op.name = bn + ".join";
       memset(&op.ap, 0, sizeof op.ap);
       op.ap.C = o.Cp; op.ap.HW = Hm * Wm; op.ap.ld = n1.ld;
@@ -1657,7 +1727,7 @@ struct Builder {
       if (learned) {
         op.a_ts = WS(ts.off);
         if (!take_partials(ns, op.ap.sts, op, 1)) { materialize(ns); op.a_scs = WS(ns.sc); op.a_shs = WS(ns.sh); }
-      } else op.a_x = WS(xin.off);
+      } else op.a_x = WS(xin_stored.off);
       op.a_out = WS(o.off);
       const int nsl = (o.Cp + 63) / 64;
       op.ap.nslices = nsl; op.ap.pblocks = std::max(1, std::min((Hm * Wm + 15) / 16, ((op.ap.st1.tiles > 0 || op.ap.sts.tiles > 0) ? 384 : 2048) / nsl));
@@ -1833,8 +1903,19 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.x = R.get<const float>(op.wi_x); p.pro_scale = R.get<const float>(op.wi_sc); p.pro_shift = R.get<const float>(op.wi_sh);
         p.v = R.get<float>(op.wi_v);
         p.st.part = R.get<const double>(op.st_part[0]); p.st.gamma = R.get<const float>(op.st_gamma[0]); p.st.beta = R.get<const float>(op.st_beta[0]);
-        if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_in, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_wino_in, op.grid, dim3(256), 0, st, p);
+        p.slab = R.get<const float>(op.wi_slab); p.sbias = R.get<const float>(op.wi_sbias);
+        p.x2 = R.get<const float>(op.wi_x2); p.xres = R.get<const float>(op.wi_xres); p.o = R.get<float>(op.wi_o);
+        p.pro2_scale = R.get<const float>(op.wi_sc2); p.pro2_shift = R.get<const float>(op.wi_sh2);
+        p.st2.part = R.get<const double>(op.st_part[1]); p.st2.gamma = R.get<const float>(op.st_gamma[1]); p.st2.beta = R.get<const float>(op.st_beta[1]);
+        if (op.wino_m == 4) {
+          if (op.wi_mode == WSRC_SPADE) hipLaunchKernelGGL(k_wino4_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
+          else if (op.wi_mode == WSRC_JOIN) hipLaunchKernelGGL(k_wino4_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL(k_wino4_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
+        } else {
+          if (op.wi_mode == WSRC_SPADE) hipLaunchKernelGGL(k_wino_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
+          else if (op.wi_mode == WSRC_JOIN) hipLaunchKernelGGL(k_wino_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL(k_wino_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
+        }
       } break;
       case OP_WINO_OUT: {
         WinoOutParams p = op.wo;

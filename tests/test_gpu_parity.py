@@ -275,8 +275,11 @@ def test_bf16_storage_mode_error_is_bounded():
     """BASELINE configs[2] mode: bf16 NHWC activations and filters in HBM / LDS, bf16 matrix-core operands, fp32
     accumulation, fp32 InstanceNorm statistics (of the rounded tensors) and fp32 SPADE arithmetic.  The reference has
     no counterpart (fp32 only), so the tolerance is this mode's own: every stored tensor is rounded to 8 mantissa bits
-    (2^-9 relative) and the error grows to ~1.5 % over the ~40 layers of the deepest path (tools/precision_debug.py);
-    a pure-bf16 torch forward deviates 1e-1 / 2e-2.  The measured error is written to gpurun_out/."""
+    (2^-9 relative) and the error grows to ~1.5 % over the ~40 layers of the deepest path (tools/precision_debug.py).
+    That is the FORMAT's error, not the kernels': a CPU model that rounds exactly the tensors and filters the kernels
+    round (tools/probes/bf16_policy_sim.py) lands on the same 1.0e-1 max / 8.7e-3 mean, and no cheap subset of the
+    roundings carries it.  Bounds = 1.5 x the measured error (written to gpurun_out/), so a regression of the
+    arithmetic - an fp32 accumulation or a statistic lost to bf16 - fails the test."""
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
     sd = synth.make_state_dict(spec, 0)
@@ -293,7 +296,8 @@ def test_bf16_storage_mode_error_is_bounded():
         m_img = float((img.cpu() - oimg).abs().mean()); m_mask = float((mask.cpu() - omask).abs().mean())
         rep["%dx%dx%d" % (B, H, W)] = {"max_abs_img": d_img, "max_abs_mask": d_mask, "mean_abs_img": m_img, "mean_abs_mask": m_mask}
         if H >= 48:      # (a 1x1 deepest map makes InstanceNorm degenerate: compared loosely in fp32 too)
-            assert d_img <= 2e-1 and d_mask <= 8e-2 and m_img <= 2e-2 and m_mask <= 1e-2, (B, H, W, d_img, d_mask, m_img, m_mask)
+            # measured (round 3): img 9.6e-2 / 1.10e-1 max, 8.2e-3 / 9.9e-3 mean; mask 2.8e-2 / 3.0e-2 max, 3.6e-3 / 4.0e-3 mean
+            assert d_img <= 1.7e-1 and d_mask <= 4.5e-2 and m_img <= 1.5e-2 and m_mask <= 6e-3, (B, H, W, d_img, d_mask, m_img, m_mask)
         assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(mask).all())
     with open("gpurun_out/parity_bf16_256.json", "w") as f:
         json.dump(rep, f)
@@ -615,11 +619,13 @@ def test_config3_32_frame_chain_512_fp32_and_bf16_against_the_oracle_loop():
     db = [float((fb[t].cpu() - ofuses[t]).abs().max()) for t in range(T)]
     mb = [float((fb[t].cpu() - ofuses[t]).abs().mean()) for t in range(T)]
     rep["bf16"] = {"max_abs_last_frame": db[-1], "max_abs_any_frame": max(db), "mean_abs_last_frame": mb[-1], "mean_abs_worst_frame": max(mb),
-                   "bound_max_abs": 2.5e-1, "bound_mean_abs": 2e-2}
+                   "bound_max_abs": 2.0e-1, "bound_mean_abs": 1.3e-2}      # 1.5 x measured (1.30e-1 worst frame, 8.4e-3 worst mean)
     with open("gpurun_out/parity_config3_chain32_512.json", "w") as f:
         json.dump(rep, f, indent=1)
     assert max(d) <= NORTH_STAR_TOL, rep["fp32"]
-    assert max(db) <= 2.5e-1 and max(mb) <= 2e-2, rep["bf16"]
+    assert max(db) <= 2.0e-1 and max(mb) <= 1.3e-2, rep["bf16"]
+    # no build-up through the recurrence: the last frame is no worse than the worst one of the first four
+    assert db[-1] <= 1.5 * max(db[:4]) and mb[-1] <= 1.5 * max(mb[:4]), (db[:4], db[-1], mb[:4], mb[-1])
     del Gb
 
 
@@ -643,6 +649,24 @@ def test_config5_1024_batch4_matches_the_batch1_run():
     assert all(v[0] <= 1e-4 and v[1] <= 1e-4 for v in rep.values()), rep
     assert float(i4.abs().max()) <= 1.0 and 0.0 <= float(m4.min()) and float(m4.max()) <= 1.0
     G._ws.clear()
+    # SURVEY 8(d) config 5 is "fp32 AND bf16": the same batch through the bf16 storage mode (its own plan: 64-channel
+    # chunks, its own tuning table) against the fp32 run above, which is oracle-pinned; samples 0 and 3; the mode's own
+    # bound (1.5 x measured, as in test_bf16_storage_mode_error_is_bounded)
+    Gb = rib.Generator(rib.hsm_gen_config(), compute_dtype="bf16").eval()
+    Gb.load_state_dict(sd)
+    ib, mb = Gb(label, None, fake, prev)
+    brep = {}
+    for b in (0, 3):
+        brep[b] = {"max_abs_img": float((ib[b] - i4[b]).abs().max()), "mean_abs_img": float((ib[b] - i4[b]).abs().mean()),
+                   "max_abs_mask": float((mb[b] - m4[b]).abs().max()), "mean_abs_mask": float((mb[b] - m4[b]).abs().mean())}
+    with open("gpurun_out/parity_config5_1024_b4.json", "w") as f:
+        json.dump({"max_abs_vs_batch1 (img, mask)": rep, "tolerance": 1e-4,
+                   "bf16_vs_fp32_batch4": brep, "bf16_bounds": {"max_abs_img": 2.5e-1, "mean_abs_img": 1.5e-2, "max_abs_mask": 5.5e-2, "mean_abs_mask": 6.2e-3}}, f)
+    assert bool(torch.isfinite(ib).all()) and bool(torch.isfinite(mb).all())
+    # measured (round 3): img 1.64e-1 / 1.49e-1 max, 1.01e-2 / 1.00e-2 mean; mask 3.6e-2 / 3.4e-2 max, 4.1e-3 mean (4 M pixels per sample:
+    # the maximum over 16x the pixels of a 256x256 frame sits further out in the same error distribution)
+    assert all(v["max_abs_img"] <= 2.5e-1 and v["mean_abs_img"] <= 1.5e-2 and v["max_abs_mask"] <= 5.5e-2 and v["mean_abs_mask"] <= 6.2e-3 for v in brep.values()), brep
+    del Gb
     torch.cuda.empty_cache()
 
 
