@@ -2586,14 +2586,15 @@ __global__ __launch_bounds__(256) void k_quantise(const float* img, uint8_t* out
 // Bilinear flow warp == grid_sample(img, base + flow*2/(size-1), bilinear, border, align_corners=True)
 // i.e. sample img at (x + fx, y + fy) in pixel units with border clamping.  Extension op (the north star
 // names it, the reference has no such call), pinned to torch's grid_sample.
-// A workgroup owns a 16 x 16 tile of OUTPUT pixels and stages the (16 + 2R) x (16 + 2R) window of the source around
-// it (R = WARP_R pixels of flow reach, all channels, border-clamped coordinates) in LDS with reads that are coalesced
-// along x within each channel plane (the driver holds frames NCHW, as the reference does: x-contiguous planes; for
-// C = 3 that is the coalesced order - an interleaved NHWC frame would be 12-byte pixels).  A pixel whose four taps
-// fall inside the window reads them from LDS (each source pixel is fetched from HBM once per tile instead of up to
-// four times per channel through the vector cache); a pixel whose flow reaches further than R falls back to global
-// loads, so any flow field is handled.  Same arithmetic on both paths.  grid (tilesX * tilesY, B), block 256.
-enum { WARP_R = 8, WARP_T = 16, WARP_WIN = WARP_T + 2 * WARP_R };
+// A workgroup owns a 32 x 32 tile of OUTPUT pixels (four per thread) and stages the (32 + 2R) x (32 + 2R) window of the
+// source around it (R = WARP_R pixels of flow reach, all channels, border-clamped coordinates) in LDS: 2.25 source pixels
+// read per output pixel (round 2's 16 x 16 tiles: 4), as 16-byte loads along x where the window lies inside the image (the
+// driver holds frames NCHW, as the reference does: x-contiguous planes; for C = 3 that is the coalesced order - an
+// interleaved NHWC frame would be 12-byte pixels).  A pixel whose four taps fall inside the window reads them from LDS
+// (each source pixel is fetched once per tile instead of up to four times per channel through the vector cache); a pixel
+// whose flow reaches further than R falls back to global loads, so any flow field is handled.  Same arithmetic on both
+// paths.  grid (tilesX * tilesY, B), block 256.
+enum { WARP_R = 8, WARP_T = 32, WARP_WIN = WARP_T + 2 * WARP_R };
 
 __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flow, float* out,
                                               int C, int H, int W, int tilesX) {
@@ -2604,40 +2605,67 @@ __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flo
   const int wy0 = ty0 - WARP_R, wx0 = tx0 - WARP_R;
   const int HW = H * W;
   const float* src = img + (size_t)n * C * HW;
-  for (int i = threadIdx.x; i < C * WARP_WIN * WARP_WIN; i += 256) {
-    const int c = i / (WARP_WIN * WARP_WIN), r = i % (WARP_WIN * WARP_WIN);
-    const int wy = r / WARP_WIN, wx = r % WARP_WIN;
-    const int sy = min(max(wy0 + wy, 0), H - 1), sx = min(max(wx0 + wx, 0), W - 1);   // border padding = clamped coordinates
-    s_win[(c * WARP_WIN + wy) * PITCH + wx] = src[(size_t)c * HW + sy * W + sx];
+  if (wx0 >= 0 && wx0 + WARP_WIN <= W && (W & 3) == 0) {
+    // interior in x: rows of the window are 16-byte aligned runs of the image rows (wx0 is a multiple of 8)
+    constexpr int Q = WARP_WIN / 4;
+    for (int i = threadIdx.x; i < C * WARP_WIN * Q; i += 256) {
+      const int c = i / (WARP_WIN * Q), r = i % (WARP_WIN * Q);
+      const int wy = r / Q, q = r % Q;
+      const int sy = min(max(wy0 + wy, 0), H - 1);
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * HW + (size_t)sy * W + wx0 + q * 4);
+      float* d = s_win + (c * WARP_WIN + wy) * PITCH + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < C * WARP_WIN * WARP_WIN; i += 256) {
+      const int c = i / (WARP_WIN * WARP_WIN), r = i % (WARP_WIN * WARP_WIN);
+      const int wy = r / WARP_WIN, wx = r % WARP_WIN;
+      const int sy = min(max(wy0 + wy, 0), H - 1), sx = min(max(wx0 + wx, 0), W - 1);   // border padding = clamped coordinates
+      s_win[(c * WARP_WIN + wy) * PITCH + wx] = src[(size_t)c * HW + sy * W + sx];
+    }
   }
   __syncthreads();
-  const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
-  if (y >= H || x >= W) return;
-  const int pix = y * W + x;
-  // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
-  const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 0) * HW + pix] * (W > 1 ? 2.f / (W - 1) : 0.f);
-  const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 1) * HW + pix] * (H > 1 ? 2.f / (H - 1) : 0.f);
-  float sx = (gx + 1.f) * 0.5f * (W - 1);
-  float sy = (gy + 1.f) * 0.5f * (H - 1);
-  sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
-  sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
-  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-  const float ax = sx - x0, ay = sy - y0;
-  const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
-  // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
-  const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
-  const bool in_win = lx0 >= 0 && lx1 < WARP_WIN && ly0 >= 0 && ly1 < WARP_WIN;
-  for (int c = 0; c < C; ++c) {
-    float v00, v01, v10, v11;
-    if (in_win) {
-      const float* wsrc = s_win + c * WARP_WIN * PITCH;
-      v00 = wsrc[ly0 * PITCH + lx0]; v01 = wsrc[ly0 * PITCH + lx1]; v10 = wsrc[ly1 * PITCH + lx0]; v11 = wsrc[ly1 * PITCH + lx1];
-    } else {
-      const float* p = src + (size_t)c * HW;
-      v00 = p[y0 * W + x0]; v01 = p[y0 * W + x1]; v10 = p[y1 * W + x0]; v11 = p[y1 * W + x1];
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int x = tx0 + lx;
+  if (x >= W) return;
+  // the flows of this thread's four pixels first (independent loads), then the taps
+  float fxv[4], fyv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = min(ty0 + ly + 8 * k, H - 1);
+    fxv[k] = flow[((size_t)n * 2 + 0) * HW + y * W + x];
+    fyv[k] = flow[((size_t)n * 2 + 1) * HW + y * W + x];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = ty0 + ly + 8 * k;
+    if (y >= H) break;
+    const int pix = y * W + x;
+    // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
+    const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + fxv[k] * (W > 1 ? 2.f / (W - 1) : 0.f);
+    const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + fyv[k] * (H > 1 ? 2.f / (H - 1) : 0.f);
+    float sx = (gx + 1.f) * 0.5f * (W - 1);
+    float sy = (gy + 1.f) * 0.5f * (H - 1);
+    sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
+    sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float ax = sx - x0, ay = sy - y0;
+    const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+    // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
+    const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
+    const bool in_win = lx0 >= 0 && lx1 < WARP_WIN && ly0 >= 0 && ly1 < WARP_WIN;
+    for (int c = 0; c < C; ++c) {
+      float v00, v01, v10, v11;
+      if (in_win) {
+        const float* wsrc = s_win + c * WARP_WIN * PITCH;
+        v00 = wsrc[ly0 * PITCH + lx0]; v01 = wsrc[ly0 * PITCH + lx1]; v10 = wsrc[ly1 * PITCH + lx0]; v11 = wsrc[ly1 * PITCH + lx1];
+      } else {
+        const float* p = src + (size_t)c * HW;
+        v00 = p[y0 * W + x0]; v01 = p[y0 * W + x1]; v10 = p[y1 * W + x0]; v11 = p[y1 * W + x1];
+      }
+      out[((size_t)n * C + c) * HW + pix] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
     }
-    out[((size_t)n * C + c) * HW + pix] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
   }
 }
 

@@ -107,7 +107,10 @@ struct ConvDef {
   size_t w16_off = 0, wp16_off = 0;
   // Winograd F(2x2, 3x3) filters U = G g G^T, [16 positions][CoutPad][CinPad] fp32, and a zero bias vector for the
   // batched GEMM (the real bias is added by the output transform); 0: the layer never runs that way
-  size_t wu_off = 0, wu4_off = 0, zero_off = 0;   // Winograd-domain filters: F(2x2,3x3) [16][coutp][cinp], F(4x4,3x3) [36][coutp][cinp]
+  // Winograd: the layer may run in the Winograd domain (wino_ok); the transformed filter sets U = G g G^T live OUTSIDE the
+  // blob, made on the device from the folded filters when a plan first needs one (WinoSet, ensure_wino_set); zero_off: a
+  // zero bias vector for the batched GEMM (the real bias is added by the output transform)
+  bool wino_ok = false; size_t zero_off = 0;
   size_t wl_off = 0; int lowc_ce = 0, lowc_ncol = 0;   // k_conv_lowc filter [9*CE/KG][KG][NCOL] (real-channel K order), CE / NCOL of its instantiation
 };
 
@@ -361,7 +364,7 @@ enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
-enum PtrSpace { PS_NULL = 0, PS_WS, PS_WEIGHT, PS_USER };
+enum PtrSpace { PS_NULL = 0, PS_WS, PS_WEIGHT, PS_USER, PS_WINO };   // PS_WINO: off = index of a Winograd filter set of the handle
 enum UserSlot { U_LABEL = 0, U_FAKE, U_PREV, U_IMG, U_MASK, U_FUSE, U_COUNT };   // U_FUSE: optional fused frame (null: no blend)
 struct PRef {
   PtrSpace sp = PS_NULL;
@@ -484,6 +487,12 @@ struct rib_handle {
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
   uint64_t layout_hash = 0;       // of the blob's offsets (assign_weight_layout); part of the blob header
+  // Winograd-domain filter sets U = G g G^T, [positions][CoutPad][CinPad] fp32 each, made on the device from the folded
+  // filters of the blob when a plan first asks for one (round 3: they were 391 of the blob's 514 MB, both sets of every layer,
+  // folded on the host, uploaded and broadcast; a 512x512 frame uses 17 of the 34)
+  struct WinoSet { int conv = 0, wm = 0; float* d = nullptr; size_t floats = 0; };
+  std::vector<WinoSet> wino_sets;
+  std::map<std::pair<int, int>, int> wino_index;
   bool weights_ready = false;
   bool compute_bf16 = false;   // rib_set_compute_dtype: bf16 storage + bf16 matrix cores
   int prec() const { return compute_bf16 ? PREC_BF16 : PREC_F32; }
@@ -519,6 +528,84 @@ int fail(rib_handle* h, int code, const std::string& msg) {
 
 const ConvDef& conv_of(const rib_handle* h, const std::string& name) {
   return h->convs[h->conv_index.at(name)];
+}
+
+// ------------------------------------------------------------------------------------------
+// Winograd-domain filter sets, made on the device from the folded 3x3 filters
+// ------------------------------------------------------------------------------------------
+// U[xi = T r + q][o][i] = (G g G^T)[r][q], T = m + 2, g[dy][dx] = w[o][dy*3+dx][i] (the blob's [CoutPad][9][CinPad] layout; padded
+// rows / columns are zeros and stay zeros).  fp64 with the roundings of the plain expression (no contraction), stored fp32.
+// F(2x2): G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  F(4x4): Cook-Toom with the points {0, +-3/4, +-3/2, inf}
+// (kernels.hip.h, k_wino4_in): G[j] = (1, a_j, a_j^2) / prod_{k != j} (a_j - a_k), last row (0, 0, 1).
+__global__ __launch_bounds__(256) void k_wino_filters(const float* w, float* u, int coutp, int cinp, int wm) {
+#pragma clang fp contract(off)
+  const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const double G4[6][3] = {{64.0 / 81, 0, 0},
+                           {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                           {32.0 / 243, 16.0 / 81, 8.0 / 27},     {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                           {0, 0, 1}};
+  const int T = wm + 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)coutp * cinp) return;
+  const int o = (int)(idx / cinp), i = (int)(idx % cinp);
+  double g[3][3], t[6][3];
+  for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = (double)w[((size_t)o * 9 + k) * cinp + i];
+  for (int r = 0; r < T; ++r)
+    for (int dx = 0; dx < 3; ++dx) {
+      const double* Gr = wm == 2 ? G2[r] : G4[r];
+      t[r][dx] = Gr[0] * g[0][dx] + Gr[1] * g[1][dx] + Gr[2] * g[2][dx];
+    }
+  for (int r = 0; r < T; ++r)
+    for (int q = 0; q < T; ++q) {
+      const double* Gq = wm == 2 ? G2[q] : G4[q];
+      u[((size_t)(r * T + q) * coutp + o) * cinp + i] = (float)(t[r][0] * Gq[0] + t[r][1] * Gq[1] + t[r][2] * Gq[2]);
+    }
+}
+
+// (re)compute set `si` from the blob on `st`; the caller orders it against whatever reads the set
+int fill_wino_set(rib_handle* h, int si, hipStream_t st) {
+  rib_handle::WinoSet& ws = h->wino_sets[si];
+  const ConvDef& c = h->convs[ws.conv];
+  if (!ws.d || !h->d_blob) return RIB_OK;
+  const size_t n = (size_t)c.coutp * c.cinp;
+  hipLaunchKernelGGL(k_wino_filters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d_blob + c.w_off, ws.d, c.coutp, c.cinp, ws.wm);
+  HIP_TRY(h, hipGetLastError());
+  return RIB_OK;
+}
+
+// index of the F(wm x wm) filter set of conv `ci`, created on first use (plan build): device memory + the transform when the
+// weights are already there.  Synchronises the device once per new set (plan builds are one-time work).  < 0: error (h->err).
+int ensure_wino_set(rib_handle* h, int ci, int wm) {
+  auto it = h->wino_index.find({ci, wm});
+  if (it != h->wino_index.end()) return it->second;
+  const ConvDef& c = h->convs[ci];
+  rib_handle::WinoSet ws; ws.conv = ci; ws.wm = wm; ws.floats = (size_t)(wm + 2) * (wm + 2) * c.coutp * c.cinp;
+  if (h->device >= 0) {
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ws.d), ws.floats * sizeof(float));
+    if (e != hipSuccess) { h->err = fmt("Winograd filter set of %s: %s", c.name.c_str(), hipGetErrorString(e)); return -1; }
+  }
+  const int si = (int)h->wino_sets.size();
+  h->wino_sets.push_back(ws);
+  h->wino_index[{ci, wm}] = si;
+  if (h->device >= 0 && h->weights_ready) {
+    if (fill_wino_set(h, si, nullptr) != RIB_OK) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) { h->err = "Winograd filter transform failed"; return -1; }
+  }
+  return si;
+}
+
+// after the blob changed (finalize / import): every existing set again, on `st`
+int refresh_wino_sets(rib_handle* h, hipStream_t st) {
+  for (int si = 0; si < (int)h->wino_sets.size(); ++si) {
+    const int rc = fill_wino_set(h, si, st);
+    if (rc) return rc;
+  }
+  return RIB_OK;
+}
+void free_wino_sets(rib_handle* h) {
+  for (auto& ws : h->wino_sets) if (ws.d) (void)hipFree(ws.d);
+  h->wino_sets.clear(); h->wino_index.clear();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -602,7 +689,7 @@ void assign_weight_layout(rib_handle* h) {
     }
     for (auto& sg : h->spades) sg.b_off = take(sg.npad);
   }
-  for (auto& c : h->convs) { c.wu_off = 0; c.wu4_off = 0; c.zero_off = 0; }
+  for (auto& c : h->convs) { c.wino_ok = false; c.zero_off = 0; }
   if (h->prec() == PREC_F32 && !getenv("RIB_NO_WINO")) {
     // 3x3 stride-1 convolutions with >= 128 input channels that own their launch (no fused 1x1 shortcut, no upsampled
     // input): the deep residual blocks of the generator and of the mask network
@@ -610,9 +697,8 @@ void assign_weight_layout(rib_handle* h) {
       // (measured per layer at 512x512, transforms included: 512->512 at 32x32 58 -> 38 us, 256->256 at 64x64 47-52 -> 42 us,
       // 512->256 at 64x64 95 -> 63 us; 128->128 at 64x64 gains nothing: the two transforms cost ~13 us per layer)
       if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin < 256 || c.cout < 64 || c.cinp % 32 || 128 % (c.coutp / 4)) continue;
-      // both transformed filter sets are kept: the plan picks F(4x4) or F(2x2) per layer from the map size (conv_wino)
-      c.wu_off = take((size_t)16 * c.coutp * c.cinp);
-      c.wu4_off = take((size_t)36 * c.coutp * c.cinp);
+      // the plan picks F(4x4) or F(2x2) per layer from the map size (conv_wino) and asks for that filter set then
+      c.wino_ok = true;
       c.zero_off = take(c.coutp);
     }
   }
@@ -649,7 +735,7 @@ void assign_weight_layout(rib_handle* h) {
   auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { hs ^= (v >> (8 * i)) & 0xff; hs *= 1099511628211ull; } };
   for (const auto& c : h->convs)
     for (uint64_t v : {(uint64_t)c.w_off, (uint64_t)c.b_off, (uint64_t)c.g_off, (uint64_t)c.be_off, (uint64_t)c.fb_off, (uint64_t)c.wp_off, (uint64_t)c.w16_off,
-                       (uint64_t)c.wp16_off, (uint64_t)c.wu_off, (uint64_t)c.wu4_off, (uint64_t)c.zero_off, (uint64_t)c.wl_off}) mix(v);
+                       (uint64_t)c.wp16_off, (uint64_t)c.zero_off, (uint64_t)c.wl_off}) mix(v);
   for (const auto& sg : h->spades)
     for (uint64_t v : {(uint64_t)sg.w_off, (uint64_t)sg.b_off, (uint64_t)sg.w16_off, (uint64_t)sg.w1_off, (uint64_t)sg.b1_off}) mix(v);
   mix(off);
@@ -835,7 +921,7 @@ struct Builder {
   bool runs_wino(const ConvArgs& a, int Hout, int Wout) const {
     static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
     const ConvDef& c = *a.cd;
-    return h->prec() == PREC_F32 && (c.wu_off || c.wu4_off) && !a.ups && !a.aux && !a.res_ups && !a.pair && !a.in.virt && a.y_nchw.sp == PS_NULL &&
+    return h->prec() == PREC_F32 && c.wino_ok && !a.ups && !a.aux && !a.res_ups && !a.pair && !a.in.virt && a.y_nchw.sp == PS_NULL &&
            a.y_user.sp == PS_NULL && (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2;
   }
   // would conv `cd` on an HxW map (stride 1, plain arguments) run in the Winograd domain?  (callers that want to hand it a lazy input)
@@ -1113,7 +1199,9 @@ struct Builder {
       p.tilesX = (tilesX + v->TW() - 1) / v->TW(); p.tilesY = (tilesY + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       p.act = ACT_NONE; p.ksplit = 1; p.yC = c.coutp; p.yoff = 0; p.Cout = c.coutp;
       p.w_mod = NP; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
-      op.x = WS(v_off); op.w = WT(wm == 2 ? c.wu_off : c.wu4_off); op.bias = WT(c.zero_off); op.y = WS(m_off);
+      const int set = ensure_wino_set(h, (int)(&c - h->convs.data()), wm);
+      if (set < 0) { error = gname + ": " + h->err; return false; }
+      op.x = WS(v_off); op.w = PRef(); op.w.sp = PS_WINO; op.w.off = (size_t)set; op.bias = WT(c.zero_off); op.y = WS(m_off);
       op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * NP);
       op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 or 1/4 of it)
       P->flops[RIB_KC_IGEMM] += op.flops;
@@ -1798,10 +1886,12 @@ Plan* get_plan(rib_handle* h, int B, int H, int W, int flags = 0, int tuneB = 0)
 // ------------------------------------------------------------------------------------------
 struct Resolver {
   char* ws; float* blob; const void* user[U_COUNT];
+  const rib_handle* h = nullptr;     // for PS_WINO
   template <typename T> T* get(const PRef& r) const {
     switch (r.sp) {
       case PS_WS: return reinterpret_cast<T*>(ws + r.off);
       case PS_WEIGHT: return reinterpret_cast<T*>(blob + r.off);
+      case PS_WINO: return reinterpret_cast<T*>(h->wino_sets[r.off].d);
       case PS_USER: return reinterpret_cast<T*>(const_cast<void*>(user[r.off]));
       default: return nullptr;
     }
@@ -2001,6 +2091,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 void rib_destroy(rib_handle* h) {
   if (!h) return;
   if (h->d_blob) (void)hipFree(h->d_blob);
+  free_wino_sets(h);
   for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
   delete h;
 }
@@ -2149,32 +2240,6 @@ int rib_finalize_weights(rib_handle* h) {
     }
     (void)KG;   // (step s, slot j) = (k / KG, k % KG): the rows are already in k order
   }
-  for (auto& c : h->convs) {
-    if (!c.used || !c.wu_off) continue;
-    // U[xi = T r + q] = (G g G^T)[r][q], T = m + 2, from the folded filters (g[dy][dx] = w[o][dy*3+dx][i]); fp64, stored fp32.
-    // F(2x2): G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  F(4x4): Cook-Toom with the points {0, +-3/4, +-3/2, inf}
-    // (kernels.hip.h, k_wino4_in): G[j] = (1, a_j, a_j^2) / prod_{k != j} (a_j - a_k), last row (0, 0, 1).
-    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    static const double G4[6][3] = {{64.0 / 81, 0, 0},
-                                    {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
-                                    {32.0 / 243, 16.0 / 81, 8.0 / 27},     {32.0 / 243, -16.0 / 81, 8.0 / 27},
-                                    {0, 0, 1}};
-    for (int wm = 2; wm <= 4; wm += 2) {
-    const int T = wm + 2;
-    const double (*G)[3] = wm == 2 ? G2 : G4;
-    const size_t u_off = wm == 2 ? c.wu_off : c.wu4_off;
-    for (int o = 0; o < c.cout; ++o)
-      for (int i = 0; i < c.cin; ++i) {
-        double g[3][3], t[6][3];
-        for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = blob[c.w_off + ((size_t)o * 9 + k) * c.cinp + i];
-        for (int r = 0; r < T; ++r)
-          for (int dx = 0; dx < 3; ++dx) t[r][dx] = G[r][0] * g[0][dx] + G[r][1] * g[1][dx] + G[r][2] * g[2][dx];
-        for (int r = 0; r < T; ++r)
-          for (int q = 0; q < T; ++q)
-            blob[u_off + ((size_t)(r * T + q) * c.coutp + o) * c.cinp + i] = (float)(t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2]);
-      }
-    }
-  }
   if (h->mc16()) {
     // rows of `rowlen` K-contiguous elements: [row][rowlen] bf16
     auto to16 = [&](size_t src, size_t dst, size_t rows, size_t rowlen) {
@@ -2200,6 +2265,9 @@ int rib_finalize_weights(rib_handle* h) {
     }
     HIP_TRY(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     h->weights_ready = true;
+    const int rcw = refresh_wino_sets(h, nullptr);      // sets that plans already use follow the new weights
+    if (rcw) return rcw;
+    HIP_TRY(h, hipDeviceSynchronize());
   }
   // the host copies stay (138 MB at HSM.yaml's size): a later rib_set_tensor of a SUBSET of the tensors followed by
   // rib_finalize_weights (load_state_dict(strict=False), a fine-tuned head) folds the new values with the old ones
@@ -2242,7 +2310,7 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
   }
   HIP_TRY(h, hipMemcpyAsync(h->d_blob, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(hip_stream)));
   h->weights_ready = true;
-  return RIB_OK;
+  return refresh_wino_sets(h, reinterpret_cast<hipStream_t>(hip_stream));      // stream-ordered behind the copy
 }
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
@@ -2253,6 +2321,7 @@ int rib_set_compute_dtype(rib_handle* h, int dtype) {
   // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
   // exported by a handle of the same storage type.
   h->plans.clear();
+  free_wino_sets(h);       // (plans reference them by index; the bf16 mode has none)
   h->choices.clear();      // tuned variant indices belong to the previous precision's kernels: back to the cost model until re-pinned
   h->compute_bf16 = dtype == RIB_DTYPE_BF16;
   assign_weight_layout(h);
@@ -2297,7 +2366,7 @@ int rib_forward_blend(rib_handle* h, int B, int H, int W, const float* label, co
   Plan* P = get_plan(h, B, H, W);
   if (!P) return RIB_ERR_INVALID;
   if (workspace_bytes < P->ws_bytes) return fail(h, RIB_ERR_WORKSPACE, fmt("workspace %zu < required %zu bytes", workspace_bytes, P->ws_bytes));
-  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
+  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob; R.h = h;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
   R.user[U_FUSE] = nullptr;
   bool fused = false;       // does the plan's mask head carry the blend?
@@ -2335,7 +2404,11 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
   const int tilesX = (W + WARP_T - 1) / WARP_T, tilesY = (H + WARP_T - 1) / WARP_T;
-  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);
+  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);      // 9.4 KB per channel
+  if (lds > 48 * 1024) {      // beyond the default dynamic-LDS limit (C >= 6): raise it once
+    static bool raised = false;
+    if (!raised) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_warp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WARP_WIN * (WARP_WIN + 1) * (int)sizeof(float))); raised = true; }
+  }
   hipLaunchKernelGGL(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
@@ -2459,7 +2532,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
     const size_t off = align256(need);
     if (workspace_bytes >= off + PL->ws_bytes) {
       lws = wsb + off;
-      Resolver RL; RL.ws = lws; RL.blob = h->d_blob;
+      Resolver RL; RL.ws = lws; RL.blob = h->d_blob; RL.h = h;
       for (int u = 0; u < U_COUNT; ++u) RL.user[u] = nullptr;
       RL.user[U_LABEL] = labels;
       rc = run_plan(h, PL, RL, st);
@@ -2485,7 +2558,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
     float* img_t = imgs ? imgs + (size_t)t * frame : tmp_img;
     float* mask_t = masks ? masks + (size_t)t * mframe : tmp_mask;
     float* fuse_t = fuses + (size_t)t * frame;
-    Resolver R; R.ws = wsb; R.blob = h->d_blob;
+    Resolver R; R.ws = wsb; R.blob = h->d_blob; R.h = h;
     R.user[U_LABEL] = labels + (size_t)t * lframe; R.user[U_FAKE] = dains + (size_t)t * frame; R.user[U_PREV] = prev;
     R.user[U_IMG] = img_t; R.user[U_MASK] = mask_t;
     R.user[U_FUSE] = chain_fused ? fuse_t : nullptr;     // the mask head writes the blend itself when it can
@@ -2652,7 +2725,7 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   for (const Op& op : P->ops)
     if (op.name == nm || op.name == nm + ".splitk_sum" || op.name == nm + ".modulate" || op.for_op == nm) sub.ops.push_back(op);
   if (sub.ops.empty()) return fail(h, RIB_ERR_INVALID, fmt("rib_time_op: no op named '%s'", op_name));
-  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob;
+  Resolver R; R.ws = reinterpret_cast<char*>(workspace); R.blob = h->d_blob; R.h = h;
   R.user[U_LABEL] = label; R.user[U_FAKE] = img_fake; R.user[U_PREV] = img_prev; R.user[U_IMG] = img; R.user[U_MASK] = mask;
   R.user[U_FUSE] = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);

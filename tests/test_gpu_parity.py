@@ -194,9 +194,10 @@ def test_warp_extension_matches_grid_sample():
     ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
     out = G.warp(img, flow).cpu()
     assert float((out - ref).abs().max()) <= 2e-5
-    # k_warp stages a window of 8 pixels of flow reach around each 16x16 output tile in LDS; flows that reach further
-    # take the global-load path.  Sizes that do not tile evenly, flows far beyond the window and beyond the frame.
-    for (B, H, W, amp, seed) in ((1, 50, 70, 7.9, 1), (2, 50, 70, 120.0, 2), (1, 17, 33, 40.0, 3), (1, 128, 128, 16.0, 4)):
+    # k_warp stages a window of 8 pixels of flow reach around each 32x32 output tile in LDS (16-byte loads where the window
+    # lies inside the image in x, scalar clamped loads at the borders); flows that reach further take the global-load path.
+    # Sizes that do not tile evenly, flows far beyond the window and beyond the frame, interior tiles (96x160).
+    for (B, H, W, amp, seed) in ((1, 50, 70, 7.9, 1), (2, 50, 70, 120.0, 2), (1, 17, 33, 40.0, 3), (1, 128, 128, 16.0, 4), (2, 96, 160, 5.0, 5)):
         g = torch.Generator().manual_seed(seed)
         img = synth.smooth_image(spec, B, H, W, 70 + seed)
         flow = (torch.rand(B, 2, H, W, generator=g) - 0.5) * 2 * amp
@@ -208,6 +209,13 @@ def test_warp_extension_matches_grid_sample():
         assert float((out - ref).abs().max()) <= 5e-5, (B, H, W, amp)
     # zero flow is the identity (up to the fp32 un-normalisation of the sampling grid)
     assert float((G.warp(img, torch.zeros_like(flow)).cpu() - img).abs().max()) <= 1e-4
+    # eight channels: the window (75 KB) is beyond the default dynamic-LDS limit
+    img8 = torch.rand(1, 8, 96, 160, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    flow8 = (torch.rand(1, 2, 96, 160, generator=torch.Generator().manual_seed(10)) - 0.5) * 10
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, 96), torch.linspace(-1, 1, 160), indexing="ij")
+    grid = torch.stack([xs, ys], -1)[None] + torch.stack([flow8[:, 0] * 2 / 159, flow8[:, 1] * 2 / 95], -1)
+    ref8 = torch.nn.functional.grid_sample(img8, grid, mode="bilinear", padding_mode="border", align_corners=True)
+    assert float((G.warp(img8, flow8).cpu() - ref8).abs().max()) <= 5e-5
 
 
 def test_weight_export_import_roundtrip_is_bit_exact():
