@@ -53,9 +53,9 @@ def parse_args(argv=None):
                          "segment of --frames dependent frames per step (configs[2] shape); clips: each rank renders its own "
                          "--frames-frame clip per step and the replicas are checked against a 1-GPU run (configs[3])")
     ap.add_argument("--frames", type=int, default=32)
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 (default, the reference's arithmetic) or bf16 (BASELINE configs[2]: bf16 storage; a separately "
-                         "reported mode)")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32",
+                    help="f32 (default, the reference's arithmetic), bf16 (BASELINE configs[2]: bf16 storage) or f16 (the same "
+                         "16-bit kernels with IEEE half elements); the 16-bit modes are separately reported, never the headline")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frames in flight per GPU: each on its own HIP stream with its own handle and "
                          "workspace (segments between key frames are independent, SURVEY F9); every forward stays batch=B")
@@ -282,12 +282,12 @@ def main():
                 rocprof_basis = {"source": "profiles/%s_prof_ops_512.json (rocprofv3 --kernel-trace of tools/prof_ops.py --run; not measured in this run)" % tag,
                                  "class_us_per_step": us, "launches_per_step": nl, "avg_launch_us": us / nl,
                                  "achieved_tflops": flops["igemm"] / (us * 1e-6) / 1e12, "frac": flops["igemm"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
-    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
     # fused-minimum HBM model of SURVEY 8(d) (every conv reads its input and writes its output once, one extra read per
     # normalised tensor, one cond read per SPADE layer, weights once): 2.82 GB per 512x512 fp32 frame, of which 0.123 GB
     # are weights; activations scale with the pixel count, bf16 storage halves everything
     px = B * H * W / (512.0 * 512.0)
-    alg_bytes = (2.694e9 * px + 0.123e9) * (0.5 if args.dtype == "bf16" else 1.0)
+    alg_bytes = (2.694e9 * px + 0.123e9) * (0.5 if args.dtype != "f32" else 1.0)
     hbm_gbs = alg_bytes * (frames_per_step / B) / (ms_per_step * 1e-3) / 1e9
     roofline = {
         "bound": "mfma",
@@ -313,8 +313,8 @@ def main():
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) * (frames_per_step / B) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
         "whole_step_algorithmic_hbm_gbs": hbm_gbs, "whole_step_frac_of_hbm_roof": hbm_gbs / PEAK_HBM_GBS,
     }
-    if args.dtype == "bf16":
-        # with bf16 matrix cores (2.5 PFLOP/s) the frame's roof is HBM (0.18 ms at 512x512): report against that;
+    if args.dtype != "f32":
+        # with 16-bit matrix cores (2.5 PFLOP/s) the frame's roof is HBM (0.18 ms at 512x512): report against that;
         # the matrix-core figures of the convolution class stay in the object for reference
         roofline.update({"bound": "hbm", "mfma_achieved_tflops": conv_tflops, "mfma_frac": conv_tflops / peak,
                          "kernel": "whole frame (the bf16 frame is bound by HBM, not by any one kernel): fused-minimum bytes of SURVEY 8(d) / frame time",
@@ -336,7 +336,7 @@ def main():
         img, mask = G(label, None, fake, prev)
         parity = {"max_abs_img": float((img.cpu() - oimg).abs().max()),
                   "max_abs_mask": float((mask.cpu() - omask).abs().max()),
-                  "tolerance": 1e-3 if args.dtype != "bf16" else None}
+                  "tolerance": 1e-3 if args.dtype == "f32" else None}
         ts = []
         reps = max(5, args.cpu_frames)
         for _ in range(reps):
@@ -352,7 +352,7 @@ def main():
                          "(PyTorch restatement validated against the imported reference), median; `cores` = threads used"
                          % (reps, H, W, B)}
 
-    dt_name = {"f32": "fp32", "bf16": "bf16 storage"}[args.dtype]
+    dt_name = {"f32": "fp32", "bf16": "bf16 storage", "f16": "half storage"}[args.dtype]
     if args.mode == "frame":
         workload = "%dx%d single-frame generator fwd + blend, batch=%d, %s" % (H, W, B, dt_name)
     elif args.mode == "chain":

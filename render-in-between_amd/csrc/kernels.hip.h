@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #ifndef RIB_UPS_ROLL
 #define RIB_UPS_ROLL 0   // phase-decomposed upsample conv: 0 = 16 steps fully unrolled, 1 = taps of a phase rolled
@@ -49,36 +50,44 @@ __device__ __forceinline__ float blend1(float img, float m, float dain) {
   return __fadd_rn(__fmul_rn(img, m), __fmul_rn(dain, __fsub_rn(1.f, m)));
 }
 
-// ---- storage type of the activations / filters: fp32 (default, the reference's arithmetic) or bf16 (BASELINE
+// ---- storage type ST of the activations / filters: ST_F32 (default, the reference's arithmetic), ST_BF16 (BASELINE
 // configs[2]: bf16 NHWC tensors in HBM and bf16 tiles in LDS - half the bytes everywhere - bf16 matrix-core
-// operands, fp32 accumulation, fp32 InstanceNorm statistics of the ROUNDED values, fp32 SPADE arithmetic).
-// Pointers stay `float*` in the parameter structs; a BF16 kernel indexes them as 2-byte elements.
-__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float v) {      // round to nearest even (v_cvt_pk_bf16_f32)
-  const __bf16 b = (__bf16)v;
-  return __builtin_bit_cast(uint16_t, b);
+// operands, fp32 accumulation, fp32 InstanceNorm statistics of the ROUNDED values, fp32 SPADE arithmetic) or ST_F16
+// (round 3: the same 16-bit layouts and kernels with IEEE half elements and v_mfma_f32_32x32x16_f16 - 11 significant bits
+// instead of 8: the bf16 mode's error is the format's, DESIGN 6, and this network's activations and filters sit well
+// inside half's range).  Pointers stay `float*` in the parameter structs; a 16-bit kernel indexes them as 2-byte elements.
+enum { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int ST> __device__ __forceinline__ float h16_to_f32(uint16_t b) {
+  if constexpr (ST == ST_F16) return (float)__builtin_bit_cast(_Float16, b);
+  else return __uint_as_float((uint32_t)b << 16);
 }
-__device__ __forceinline__ float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
-template <bool BF16> __device__ __forceinline__ float ld_act(const float* base, size_t i) {
-  if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t*>(base)[i]);
+template <int ST> __device__ __forceinline__ uint16_t f32_to_h16(float v) {      // round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+  if constexpr (ST == ST_F16) { const _Float16 hv = (_Float16)v; return __builtin_bit_cast(uint16_t, hv); }
+  else { const __bf16 b = (__bf16)v; return __builtin_bit_cast(uint16_t, b); }
+}
+template <int ST> __device__ __forceinline__ float round16(float v) { return h16_to_f32<ST>(f32_to_h16<ST>(v)); }
+template <int ST> __device__ __forceinline__ float ld_act(const float* base, size_t i) {
+  if constexpr (ST != ST_F32) return h16_to_f32<ST>(reinterpret_cast<const uint16_t*>(base)[i]);
   else return base[i];
 }
-template <bool BF16> __device__ __forceinline__ void st_act(float* base, size_t i, float v) {
-  if constexpr (BF16) reinterpret_cast<uint16_t*>(base)[i] = f32_to_bf16(v);
+template <int ST> __device__ __forceinline__ void st_act(float* base, size_t i, float v) {
+  if constexpr (ST != ST_F32) reinterpret_cast<uint16_t*>(base)[i] = f32_to_h16<ST>(v);
   else base[i] = v;
 }
-// four consecutive elements (16 B of fp32 / 8 B of bf16)
-template <bool BF16> __device__ __forceinline__ float4 ld_act4(const float* base, size_t i) {
-  if constexpr (BF16) {
+// four consecutive elements (16 B of fp32 / 8 B of a 16-bit type)
+template <int ST> __device__ __forceinline__ float4 ld_act4(const float* base, size_t i) {
+  if constexpr (ST != ST_F32) {
     const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + i);
-    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    return make_float4(h16_to_f32<ST>((uint16_t)(r.x & 0xffffu)), h16_to_f32<ST>((uint16_t)(r.x >> 16)),
+                       h16_to_f32<ST>((uint16_t)(r.y & 0xffffu)), h16_to_f32<ST>((uint16_t)(r.y >> 16)));
   } else return *reinterpret_cast<const float4*>(base + i);
 }
-template <bool BF16> __device__ __forceinline__ void st_act4(float* base, size_t i, float4 v) {
-  if constexpr (BF16) {
+template <int ST> __device__ __forceinline__ void st_act4(float* base, size_t i, float4 v) {
+  if constexpr (ST != ST_F32) {
     uint2 r;
-    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    r.x = (uint32_t)f32_to_h16<ST>(v.x) | ((uint32_t)f32_to_h16<ST>(v.y) << 16);
+    r.y = (uint32_t)f32_to_h16<ST>(v.z) | ((uint32_t)f32_to_h16<ST>(v.w) << 16);
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + i) = r;
   } else *reinterpret_cast<float4*>(base + i) = v;
 }
@@ -204,10 +213,10 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // PREC: 0 = fp32 (exact-fp32 matrix cores), 1 = bf16 storage + bf16 matrix cores.  (Round 2's exploratory "f32x3" mode -
 // fp32 storage, operands split into three bf16 terms, six bf16 MFMAs per step - never beat fp32 once the deep layers ran
 // in the Winograd domain and was retired in round 3.)
-enum { PREC_F32 = 0, PREC_BF16 = 1 };
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };      // = ST_F32 / ST_BF16 / ST_F16
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, int PREC = 0>
 struct IgemmGeom {
-  static constexpr bool BF16 = PREC == PREC_BF16;
+  static constexpr bool BF16 = PREC != PREC_F32;      // 16-bit storage (bf16 or half): the layouts only depend on the element size
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
   static constexpr int FRH = 32 / FRW;
   static constexpr int TH = FRH * MF * WM;
@@ -274,7 +283,8 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // and fits 99-104 registers without spilling.
 __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC> G;
-  constexpr bool BF16 = G::BF16;
+  constexpr bool BF16 = G::BF16;                // 16-bit storage, bf16 or half (ST says which)
+  constexpr int ST = PREC;
   constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored activation element
   constexpr int WSZ = BF16 ? 2 : 4;     // bytes per stored filter element
   constexpr int EPS = G::EPS, GPR = G::GPR, GPRB = G::GPRB;
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
             const uint32_t w[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
             float e[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { e[2 * k] = __uint_as_float(w[k] << 16); e[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            for (int k = 0; k < 4; ++k) { e[2 * k] = h16_to_f32<ST>((uint16_t)(w[k] & 0xffffu)); e[2 * k + 1] = h16_to_f32<ST>((uint16_t)(w[k] >> 16)); }
             if (aff) {
               const float sc[8] = {psc[0].x, psc[0].y, psc[0].z, psc[0].w, psc[PV - 1].x, psc[PV - 1].y, psc[PV - 1].z, psc[PV - 1].w};
               const float sh[8] = {psh[0].x, psh[0].y, psh[0].z, psh[0].w, psh[PV - 1].x, psh[PV - 1].y, psh[PV - 1].z, psh[PV - 1].w};
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
             }
             uint32_t o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f32_to_bf16(e[2 * k]) | ((uint32_t)f32_to_bf16(e[2 * k + 1]) << 16);
+            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f32_to_h16<ST>(e[2 * k]) | ((uint32_t)f32_to_h16<ST>(e[2 * k + 1]) << 16);
             v = make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]), __uint_as_float(o[3]));
           }
         } else {
@@ -564,16 +574,19 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
 #pragma unroll
         for (int kj = 0; kj < KBW16; ++kj) {
           const int kb = kw * KBW16 + kj;
-          bf16x8 a[MF], b[NFE];
+          typedef typename std::conditional<ST == ST_F16, f16x8, bf16x8>::type op8;      // the same 16 bytes either way
+          op8 a[MF], b[NFE];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const bf16x8*>(sA + aoff[mf] + kb * 8 + lh * 4);
+          for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const op8*>(sA + aoff[mf] + kb * 8 + lh * 4);
 #pragma unroll
-          for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(sBrow + nf * 32 * G::CK + kb * 8 + lh * 4);
+          for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const op8*>(sBrow + nf * 32 * G::CK + kb * 8 + lh * 4);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < NFE; ++nf)
-              acc[ph * MF + mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[ph * MF + mf][nf], 0, 0, 0);
+            for (int nf = 0; nf < NFE; ++nf) {
+              if constexpr (ST == ST_F16) acc[ph * MF + mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mf], b[nf], acc[ph * MF + mf][nf], 0, 0, 0);
+              else acc[ph * MF + mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[ph * MF + mf][nf], 0, 0, 0);
+            }
         }
         return;
       }
@@ -977,7 +990,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
             oy = min(oy, p.Hout - 1); ox = min(ox, p.Wout - 1);
             const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)
                                           : ((size_t)n * p.Hout + oy) * p.Wout + ox;
-            rv[r] = ld_act<BF16>(p.res, rpix * p.resC + min(col, p.resC - 1));
+            rv[r] = ld_act<ST>(p.res, rpix * p.resC + min(col, p.resC - 1));
           }
         }
         // values first (no memory operations, the activation chosen once per fragment), then the stores: with
@@ -1004,7 +1017,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         if constexpr (BF16) {
           if (!p.y_f32) {   // the stored tensor is bf16: the statistics describe what the consumer will read
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { vf[r] = vv[r]; vv[r] = bf16_round(vv[r]); }
+            for (int r = 0; r < 16; ++r) { vf[r] = vv[r]; vv[r] = round16<ST>(vv[r]); }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) vf[r] = vv[r];
@@ -1035,7 +1048,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
           if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
           if (okm & (1u << r)) {
             const size_t yi = (((size_t)ny * p.Hout + oy) * p.Wout + ox) * p.yC + yoff + col;
-            if constexpr (BF16) { if (p.y_f32) p.y[yi] = vv[r]; else st_act<true>(p.y, yi, vv[r]); }
+            if constexpr (BF16) { if (p.y_f32) p.y[yi] = vv[r]; else st_act<ST>(p.y, yi, vv[r]); }
             else p.y[yi] = vv[r];
           }
         }
@@ -1120,7 +1133,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
         const int ox = min(tx0 + row % FRW, p.Wout - 1);
         const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-        xr[k] = ld_act<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+        xr[k] = ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1135,7 +1148,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         if (vvalid && oy < p.Hout && ox < p.Wout) {
           float o = (xr[k] * sc + sh) * (1.f + gamma) + beta;
           o = apply_act(o, act);
-          st_act<BF16>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
+          st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
         }
       }
     }
@@ -1168,7 +1181,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
           const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
           const int ox = min(tx0 + row % FRW, p.Wout - 1);
           const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-          xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+          xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1181,7 +1194,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
             const float beta = acc[mf][2 * q + 1][r] + bb;
             float o = (xv * sc + sh) * (1.f + gamma) + beta;
             o = apply_act(o, act);
-            if (!(RIB_EXP & 16) || o == 123.456f) st_act<BF16>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
+            if (!(RIB_EXP & 16) || o == 123.456f) st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
           }
         }
       }
@@ -1265,7 +1278,7 @@ struct SplitEpiParams {
   int Hout, Wout;
 };
 
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p) {
   __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.CoutPad / 4;
@@ -1323,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       const int oy = pix / p.Wout, ox = pix % p.Wout;
       const size_t rpix = p.res_ups ? ((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1) : (size_t)n * npix + pix;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rres[k][e] = ld_act<BF16>(p.res, rpix * p.resC + min(c4 * 4 + e, p.resC - 1));
+      for (int e = 0; e < 4; ++e) rres[k][e] = ld_act<ST>(p.res, rpix * p.resC + min(c4 * 4 + e, p.resC - 1));
     }
   }
   float vals[4][4];
@@ -1337,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       float t = v[e];
       if (p.res) t += rres[k][e];
       t = apply_act(t, p.act);
-      if constexpr (BF16) t = bf16_round(t);      // statistics of the tensor as it is stored
+      if constexpr (ST != ST_F32) t = round16<ST>(t);      // statistics of the tensor as it is stored
       vals[k][e] = (pix < npix && c4 * 4 + e < p.Cout) ? t : 0.f;
     }
 #pragma unroll
@@ -1350,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const SplitEpiParams p)
       const size_t opix = (size_t)n * npix + pix;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (c4 * 4 + e < p.Cout) st_act<BF16>(p.y, opix * p.yC + p.yoff + c4 * 4 + e, vals[k][e]);
+        if (c4 * 4 + e < p.Cout) st_act<ST>(p.y, opix * p.yC + p.yoff + c4 * 4 + e, vals[k][e]);
     }
   }
   if (p.stat_part) {
@@ -1870,7 +1883,7 @@ struct ModulateParams {
   int nslices, pblocks;
 };
 
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) {
   __shared__ double red[4 * 64 * 2];
   __shared__ float s_sc[64], s_sh[64];
@@ -1921,7 +1934,7 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
       }
       const int oy = pix / p.Wout, ox = pix % p.Wout;
       const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-      x[k] = ld_act4<BF16>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
+      x[k] = ld_act4<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + c);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1932,7 +1945,7 @@ __global__ __launch_bounds__(256) void k_spade_modulate(const ModulateParams p) 
       o.y = apply_act(spade_mod1(x[k].y, sc.y, sh.y, g[k].y, bg.y, b[k].y, bb.y), act);
       o.z = apply_act(spade_mod1(x[k].z, sc.z, sh.z, g[k].z, bg.z, b[k].z, bb.z), act);
       o.w = apply_act(spade_mod1(x[k].w, sc.w, sh.w, g[k].w, bg.w, b[k].w, bb.w), act);
-      st_act4<BF16>(yout, ((size_t)n * npix + pix) * p.C + c, o);
+      st_act4<ST>(yout, ((size_t)n * npix + pix) * p.C + c, o);
     }
   }
 }
@@ -1949,7 +1962,7 @@ struct PoolParams {
   int blocks;
 };
 
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
   __shared__ __attribute__((aligned(16))) double red[2][256][4];
   const int c4n = p.C / 4;
@@ -1973,7 +1986,7 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
         const int iy = oy * 2 - 1 + t / 3, ix = ox * 2 - 1 + t % 3;
         m[t] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
         const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        v[t] = ld_act4<BF16>(p.x, xn + ((size_t)cy * p.W + cx) * p.C + c4 * 4);
+        v[t] = ld_act4<ST>(p.x, xn + ((size_t)cy * p.W + cx) * p.C + c4 * 4);
       }
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1981,8 +1994,8 @@ __global__ __launch_bounds__(256) void k_avgpool(const PoolParams p) {
         if (m[t] != 0.f) { a.x += v[t].x; a.y += v[t].y; a.z += v[t].z; a.w += v[t].w; }
       const float inv9 = 1.f / 9.f;
       a.x *= inv9; a.y *= inv9; a.z *= inv9; a.w *= inv9;
-      if constexpr (BF16) a = make_float4(bf16_round(a.x), bf16_round(a.y), bf16_round(a.z), bf16_round(a.w));
-      st_act4<BF16>(p.y, ((size_t)n * npix + pix) * p.C + c4 * 4, a);
+      if constexpr (ST != ST_F32) a = make_float4(round16<ST>(a.x), round16<ST>(a.y), round16<ST>(a.z), round16<ST>(a.w));
+      st_act4<ST>(p.y, ((size_t)n * npix + pix) * p.C + c4 * 4, a);
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += (double)av[e]; s2[e] += (double)av[e] * (double)av[e]; }
@@ -2019,7 +2032,7 @@ struct InAddParams {
   int nslices, pblocks;
 };
 
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
   __shared__ double red[4 * 64 * 2];
   __shared__ float s_sc[2][64], s_sh[2][64];
@@ -2047,8 +2060,8 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const size_t e = ((size_t)n * p.HW + min(pix0 + k * pstep, p.HW - 1)) * p.C + c4 * 4;
-      a[k] = ld_act4<BF16>(p.t1, e);
-      b[k] = ld_act4<BF16>(second, e);
+      a[k] = ld_act4<ST>(p.t1, e);
+      b[k] = ld_act4<ST>(second, e);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2057,7 +2070,7 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
       float4 o = make_float4(a[k].x * s.x + t.x, a[k].y * s.y + t.y, a[k].z * s.z + t.z, a[k].w * s.w + t.w);
       if (p.ts) { o.x += b[k].x * s2.x + t2.x; o.y += b[k].y * s2.y + t2.y; o.z += b[k].z * s2.z + t2.z; o.w += b[k].w * s2.w + t2.w; }
       else { o.x += b[k].x; o.y += b[k].y; o.z += b[k].z; o.w += b[k].w; }
-      st_act4<BF16>(p.out, ((size_t)n * p.HW + pix) * p.C + c4 * 4, o);
+      st_act4<ST>(p.out, ((size_t)n * p.HW + pix) * p.C + c4 * 4, o);
     }
   }
 }
@@ -2071,7 +2084,7 @@ __global__ __launch_bounds__(256) void k_in_add(const InAddParams p) {
 // element) and the CO x 9 x Cin filter in LDS; thread = pixel; filter reads are LDS broadcasts.
 // Uses IgemmParams (x, prologue, w [CoutPad][9][Cin], bias, y / y_nchw, act); grid (tiles, 1, B).
 // ---------------------------------------------------------------------------------------------
-template <int CO, bool BF16 = false>
+template <int CO, int ST = 0>
 __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
   const int Cin = p.Cin, CK = Cin + 4, C4 = Cin / 4;
@@ -2104,7 +2117,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
       const int idx = min(base + u * 256 + tid, total4 - 1);
       const int pix = idx / C4;
       const int iy = min(max(ty0 - 1 + pix / 18, 0), p.Hin - 1), ix = min(max(tx0 - 1 + pix % 18, 0), p.Win - 1);
-      v[u] = ld_act4<BF16>(p.x, xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
+      v[u] = ld_act4<ST>(p.x, xn + (unsigned)((iy * p.Win + ix) * p.xC + c4 * 4));
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -2143,11 +2156,11 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     const float v = apply_act(acc[co] + bias[co], p.act);
-    if (p.y) { if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v; }
+    if (p.y) { if (ST != ST_F32 && !p.y_f32) st_act<ST>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v; }
     if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
   }
   for (int co = CO; co < p.Cout && p.y; ++co) {   // channel padding, as k_igemm stores it
-    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
+    if (ST != ST_F32 && !p.y_f32) st_act<ST>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
   }
 }
 
@@ -2163,7 +2176,7 @@ __global__ __launch_bounds__(256) void k_conv_small(const IgemmParams p) {
 // For the mask head the driver's blend is fused: the thread that has the pixel's mask also writes the fused frame.
 // CIN = padded input channels (16 or 32); grid (tiles, 1, B), block 256; IgemmParams as for k_conv_small.
 // ---------------------------------------------------------------------------------------------
-template <int CO, int CIN, bool BF16 = false>
+template <int CO, int CIN, int ST = 0>
 __global__ __launch_bounds__(256) void k_conv_head(const IgemmParams p) {
   constexpr int NCOL = 9 * CO, NB = (NCOL + 15) / 16, NG = CIN / 16;
   constexpr int HW_ = 18, HPX = HW_ * HW_, NBLK = (HPX + 15) / 16, PP = HPX + 1;
@@ -2205,7 +2218,7 @@ __global__ __launch_bounds__(256) void k_conv_head(const IgemmParams p) {
     const int px = min((wave + 4 * i) * 16 + l15, HPX - 1);
     const int cy = min(max(ty0 - 1 + px / HW_, 0), p.Hin - 1), cx = min(max(tx0 - 1 + px % HW_, 0), p.Win - 1);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) areg[i][g] = ld_act4<BF16>(p.x, xn + (size_t)(unsigned)((cy * p.Win + cx) * p.xC + g * 16 + q * 4));
+    for (int g = 0; g < NG; ++g) areg[i][g] = ld_act4<ST>(p.x, xn + (size_t)(unsigned)((cy * p.Win + cx) * p.xC + g * 16 + q * 4));
   }
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
@@ -2265,11 +2278,11 @@ __global__ __launch_bounds__(256) void k_conv_head(const IgemmParams p) {
   for (int co = 0; co < CO; ++co) {
     const float v = apply_act(o[co] + p.bias[co], p.act);
     o[co] = v;
-    if (p.y) { if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v; }
+    if (p.y) { if (ST != ST_F32 && !p.y_f32) st_act<ST>(p.y, pix * p.yC + p.yoff + co, v); else p.y[pix * p.yC + p.yoff + co] = v; }
     if (p.y_nchw) p.y_nchw[(((size_t)n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = v;
   }
   for (int co = CO; co < p.Cout && p.y; ++co) {   // channel padding, as k_igemm stores it
-    if (BF16 && !p.y_f32) st_act<true>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
+    if (ST != ST_F32 && !p.y_f32) st_act<ST>(p.y, pix * p.yC + p.yoff + co, apply_act(0.f, p.act)); else p.y[pix * p.yC + p.yoff + co] = apply_act(0.f, p.act);
   }
   if constexpr (CO == 1) {
     if (p.bl_fuse) {                        // evaluator.py:256-258, same operation order as k_blend
@@ -2328,7 +2341,7 @@ struct LowcParams {
   int tilesX, tilesY;
 };
 
-template <int CE, int NCOL, bool BF16, int TW = 32>
+template <int CE, int NCOL, int ST, int TW = 32>
 __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   constexpr bool N16 = NCOL == 16;
   static_assert(NCOL == 16 || NCOL == 32 || NCOL == 64, "16-, 32- or 64-column layers");
@@ -2436,9 +2449,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
           const int oy = ty0 + wave * 2 + (TW == 32 ? mf : (m >> 4));
           const int ox = tx0 + (TW == 32 ? m : (m & 15));
           float v = apply_act(acc[mf][nf][r] + bv, p.act);
-          if (BF16) v = bf16_round(v);
+          if (ST != ST_F32) v = round16<ST>(v);
           const bool ok = cok && oy < p.H && ox < p.W;
-          if (ok) st_act<BF16>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+          if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
           v = ok ? v : 0.f;
           c1 += (double)v; c2 += (double)v * (double)v;
         }
@@ -2475,9 +2488,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       for (int r = 0; r < 4; ++r) {
         const int ox = tx0 + (TW == 32 ? (f & 1) * 16 : 0) + lq * 4 + r;
         float v = apply_act(acc[f][r] + bv, p.act);
-        if (BF16) v = bf16_round(v);
+        if (ST != ST_F32) v = round16<ST>(v);
         const bool ok = cok && oy < p.H && ox < p.W;
-        if (ok) st_act<BF16>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+        if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
         v = ok ? v : 0.f;
         s1 += (double)v; s2 += (double)v * (double)v;
       }
@@ -2517,7 +2530,7 @@ struct PackParams {
   int HW;
 };
 
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_pack(const PackParams p) {
   // 64 pixels per block.  Phase 1: thread = (pixel, channel slice) reads NCHW coalesced along the
   // pixels; phase 2, after an LDS transpose: consecutive lanes write consecutive 16 bytes of NHWC.
@@ -2541,19 +2554,19 @@ __global__ __launch_bounds__(256) void k_pack(const PackParams p) {
   for (int idx = threadIdx.x; idx < 64 * c4n; idx += 256) {
     const int q = idx / c4n, g = idx % c4n;
     if (pix0 + q < p.HW)
-      st_act4<BF16>(p.dst, ((size_t)n * p.HW + pix0 + q) * p.dC + g * 4,
+      st_act4<ST>(p.dst, ((size_t)n * p.HW + pix0 + q) * p.dC + g * 4,
                     make_float4(tile[q][g * 4], tile[q][g * 4 + 1], tile[q][g * 4 + 2], tile[q][g * 4 + 3]));
   }
 }
 
 // NHWC (channel stride sC, first C channels) -> NCHW, for taps / debugging
-template <bool BF16>
+template <int ST>
 __global__ __launch_bounds__(256) void k_unpack(const float* src, int sC, int C, int HW, int ups, int H, int W, float* dst) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (pix >= HW) return;
   (void)ups; (void)H; (void)W;
-  for (int c = 0; c < C; ++c) dst[((size_t)n * C + c) * HW + pix] = ld_act<BF16>(src, ((size_t)n * HW + pix) * sC + c);
+  for (int c = 0; c < C; ++c) dst[((size_t)n * C + c) * HW + pix] = ld_act<ST>(src, ((size_t)n * HW + pix) * sC + c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2586,15 +2599,14 @@ __global__ __launch_bounds__(256) void k_quantise(const float* img, uint8_t* out
 // Bilinear flow warp == grid_sample(img, base + flow*2/(size-1), bilinear, border, align_corners=True)
 // i.e. sample img at (x + fx, y + fy) in pixel units with border clamping.  Extension op (the north star
 // names it, the reference has no such call), pinned to torch's grid_sample.
-// A workgroup owns a 32 x 32 tile of OUTPUT pixels (four per thread) and stages the (32 + 2R) x (32 + 2R) window of the
-// source around it (R = WARP_R pixels of flow reach, all channels, border-clamped coordinates) in LDS: 2.25 source pixels
-// read per output pixel (round 2's 16 x 16 tiles: 4), as 16-byte loads along x where the window lies inside the image (the
-// driver holds frames NCHW, as the reference does: x-contiguous planes; for C = 3 that is the coalesced order - an
-// interleaved NHWC frame would be 12-byte pixels).  A pixel whose four taps fall inside the window reads them from LDS
-// (each source pixel is fetched once per tile instead of up to four times per channel through the vector cache); a pixel
-// whose flow reaches further than R falls back to global loads, so any flow field is handled.  Same arithmetic on both
-// paths.  grid (tilesX * tilesY, B), block 256.
-enum { WARP_R = 8, WARP_T = 32, WARP_WIN = WARP_T + 2 * WARP_R };
+// A workgroup owns a 16 x 16 tile of OUTPUT pixels and stages the (16 + 2R) x (16 + 2R) window of the source around
+// it (R = WARP_R pixels of flow reach, all channels, border-clamped coordinates) in LDS with reads that are coalesced
+// along x within each channel plane (the driver holds frames NCHW, as the reference does: x-contiguous planes; for
+// C = 3 that is the coalesced order - an interleaved NHWC frame would be 12-byte pixels).  A pixel whose four taps
+// fall inside the window reads them from LDS (each source pixel is fetched from HBM once per tile instead of up to
+// four times per channel through the vector cache); a pixel whose flow reaches further than R falls back to global
+// loads, so any flow field is handled.  Same arithmetic on both paths.  grid (tilesX * tilesY, B), block 256.
+enum { WARP_R = 8, WARP_T = 16, WARP_WIN = WARP_T + 2 * WARP_R };
 
 __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flow, float* out,
                                               int C, int H, int W, int tilesX) {
@@ -2605,67 +2617,40 @@ __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flo
   const int wy0 = ty0 - WARP_R, wx0 = tx0 - WARP_R;
   const int HW = H * W;
   const float* src = img + (size_t)n * C * HW;
-  if (wx0 >= 0 && wx0 + WARP_WIN <= W && (W & 3) == 0) {
-    // interior in x: rows of the window are 16-byte aligned runs of the image rows (wx0 is a multiple of 8)
-    constexpr int Q = WARP_WIN / 4;
-    for (int i = threadIdx.x; i < C * WARP_WIN * Q; i += 256) {
-      const int c = i / (WARP_WIN * Q), r = i % (WARP_WIN * Q);
-      const int wy = r / Q, q = r % Q;
-      const int sy = min(max(wy0 + wy, 0), H - 1);
-      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * HW + (size_t)sy * W + wx0 + q * 4);
-      float* d = s_win + (c * WARP_WIN + wy) * PITCH + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-  } else {
-    for (int i = threadIdx.x; i < C * WARP_WIN * WARP_WIN; i += 256) {
-      const int c = i / (WARP_WIN * WARP_WIN), r = i % (WARP_WIN * WARP_WIN);
-      const int wy = r / WARP_WIN, wx = r % WARP_WIN;
-      const int sy = min(max(wy0 + wy, 0), H - 1), sx = min(max(wx0 + wx, 0), W - 1);   // border padding = clamped coordinates
-      s_win[(c * WARP_WIN + wy) * PITCH + wx] = src[(size_t)c * HW + sy * W + sx];
-    }
+  for (int i = threadIdx.x; i < C * WARP_WIN * WARP_WIN; i += 256) {
+    const int c = i / (WARP_WIN * WARP_WIN), r = i % (WARP_WIN * WARP_WIN);
+    const int wy = r / WARP_WIN, wx = r % WARP_WIN;
+    const int sy = min(max(wy0 + wy, 0), H - 1), sx = min(max(wx0 + wx, 0), W - 1);   // border padding = clamped coordinates
+    s_win[(c * WARP_WIN + wy) * PITCH + wx] = src[(size_t)c * HW + sy * W + sx];
   }
   __syncthreads();
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-  const int x = tx0 + lx;
-  if (x >= W) return;
-  // the flows of this thread's four pixels first (independent loads), then the taps
-  float fxv[4], fyv[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = min(ty0 + ly + 8 * k, H - 1);
-    fxv[k] = flow[((size_t)n * 2 + 0) * HW + y * W + x];
-    fyv[k] = flow[((size_t)n * 2 + 1) * HW + y * W + x];
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = ty0 + ly + 8 * k;
-    if (y >= H) break;
-    const int pix = y * W + x;
-    // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
-    const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + fxv[k] * (W > 1 ? 2.f / (W - 1) : 0.f);
-    const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + fyv[k] * (H > 1 ? 2.f / (H - 1) : 0.f);
-    float sx = (gx + 1.f) * 0.5f * (W - 1);
-    float sy = (gy + 1.f) * 0.5f * (H - 1);
-    sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
-    sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
-    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    const float ax = sx - x0, ay = sy - y0;
-    const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
-    // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
-    const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
-    const bool in_win = lx0 >= 0 && lx1 < WARP_WIN && ly0 >= 0 && ly1 < WARP_WIN;
-    for (int c = 0; c < C; ++c) {
-      float v00, v01, v10, v11;
-      if (in_win) {
-        const float* wsrc = s_win + c * WARP_WIN * PITCH;
-        v00 = wsrc[ly0 * PITCH + lx0]; v01 = wsrc[ly0 * PITCH + lx1]; v10 = wsrc[ly1 * PITCH + lx0]; v11 = wsrc[ly1 * PITCH + lx1];
-      } else {
-        const float* p = src + (size_t)c * HW;
-        v00 = p[y0 * W + x0]; v01 = p[y0 * W + x1]; v10 = p[y1 * W + x0]; v11 = p[y1 * W + x1];
-      }
-      out[((size_t)n * C + c) * HW + pix] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+  const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
+  if (y >= H || x >= W) return;
+  const int pix = y * W + x;
+  // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
+  const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 0) * HW + pix] * (W > 1 ? 2.f / (W - 1) : 0.f);
+  const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 1) * HW + pix] * (H > 1 ? 2.f / (H - 1) : 0.f);
+  float sx = (gx + 1.f) * 0.5f * (W - 1);
+  float sy = (gy + 1.f) * 0.5f * (H - 1);
+  sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
+  sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  const float ax = sx - x0, ay = sy - y0;
+  const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+  // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
+  const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
+  const bool in_win = lx0 >= 0 && lx1 < WARP_WIN && ly0 >= 0 && ly1 < WARP_WIN;
+  for (int c = 0; c < C; ++c) {
+    float v00, v01, v10, v11;
+    if (in_win) {
+      const float* wsrc = s_win + c * WARP_WIN * PITCH;
+      v00 = wsrc[ly0 * PITCH + lx0]; v01 = wsrc[ly0 * PITCH + lx1]; v10 = wsrc[ly1 * PITCH + lx0]; v11 = wsrc[ly1 * PITCH + lx1];
+    } else {
+      const float* p = src + (size_t)c * HW;
+      v00 = p[y0 * W + x0]; v01 = p[y0 * W + x1]; v10 = p[y1 * W + x0]; v11 = p[y1 * W + x1];
     }
+    out[((size_t)n * C + c) * HW + pix] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
   }
 }
 

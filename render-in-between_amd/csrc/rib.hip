@@ -81,6 +81,25 @@ inline uint16_t host_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// float -> IEEE half, round to nearest even (what v_cvt_f16_f32 does on the device), subnormals and overflow to inf included
+inline uint16_t host_f16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                      // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                     // >= 65520 rounds to inf
+  if (a < 0x33000001u) return (uint16_t)sign;                                  // <= 2^-25 rounds to zero
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                                    // 24-bit significand
+  int shift = e < -14 ? 13 + (-14 - e) : 13;                                   // bits dropped (subnormal: more)
+  uint32_t half_m = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (half_m & 1u))) half_m += 1;
+  uint32_t h16;
+  if (e < -14) h16 = half_m;                                                   // subnormal (a carry into 0x400 is the smallest normal: correct)
+  else h16 = ((uint32_t)(e + 15) << 10) + (half_m - 0x400u);                   // a mantissa carry bumps the exponent: correct
+  return (uint16_t)(sign | h16);
+}
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 inline int pick_bk(int cp) { return cp % 32 == 0 ? 32 : (cp % 16 == 0 ? 16 : 8); }
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
@@ -209,7 +228,7 @@ typedef void (*IgemmFn)(const IgemmParams);
 struct Variant {
   int FRW, WM, WN, MF, NF, BK, STRIDE, KS; bool UPS, SPADE;
   IgemmFn fn;          // generic instantiation (fused-shortcut loop and input prologue compiled in)
-  int BF16 = 0;        // precision of this instantiation: PREC_F32 / PREC_BF16 (bf16 storage)
+  int BF16 = 0;        // precision of this instantiation: PREC_F32 / PREC_BF16 / PREC_F16 (16-bit storage)
   IgemmFn fn_pro = nullptr;    // without the fused-shortcut loop
   IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int KW = 1;                  // in-workgroup split-K: KW groups of 4 waves (256*KW threads) per tile
@@ -220,7 +239,7 @@ struct Variant {
   int lds_bytes() const {
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
-    const int ck = (BF16 == PREC_BF16 ? BK / 2 : BK) + 4;   // IgemmGeom::CK
+    const int ck = (BF16 != PREC_F32 ? BK / 2 : BK) + 4;   // IgemmGeom::CK
     const bool db1 = KS == 1 && TB == 2;                                                        // 1x1, everything double-buffered
     const int main_loop = (((TB == 9 || db1) ? 2 : 1) * ih * iwp * ck + 2 * (db1 ? 1 : TB) * BN() * ck) * 4;   // IgemmGeom::NA, TBB
     const int kw_reduce = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 * 4 : 0;
@@ -271,8 +290,10 @@ struct Variant {
 // per tile instead of the unfused pair (split-K GEMM into slabs + k_spade_modulate)
 #define RIB_VSK(sec, FRW, WM, WN, MF, NF, BK, KW) \
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW>, false, nullptr, nullptr, KW},
+// (every 16-bit geometry exists twice: bf16 and half elements, PREC_BF16 / PREC_F16)
 #define RIB_VB(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) \
-  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true>, true},
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 1>, 1}, \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2>, 2},
 // 1x1, everything double-buffered (TB = 2): convolution (pro / lean) and SPADE
 #define RIB_V1D(sec, FRW, WM, WN, MF, NF, BK, KW)                                                                    \
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, false,                                                               \
@@ -283,7 +304,9 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, true, true, KW, 2>, 0, nullptr, nullptr, KW, 2},
 #define RIB_VBX(sec, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB)                                                            \
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
-          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, true, nullptr, nullptr, KW, TB},
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 1, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 1, nullptr, nullptr, KW, TB}, \
+  Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
+          &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 2, nullptr, nullptr, KW, TB},
 
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
@@ -339,7 +362,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
       const int chunks = (nchunks + S - 1) / S;
       const int taps = ups ? 16 : ks * ks;
       const double mfma_tap = v.NF == 0 ? (BK / 16) * v.MF * 8 * 32.0
-                                        : (v.BF16 == PREC_BF16 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
+                                        : (v.BF16 != PREC_F32 ? (BK / 16) * v.MF * v.NF * 32.0 : (BK / 8) * v.MF * v.NF * 4 * 64.0);
       // per tap: barrier + LDS write/read latency; per chunk: halo-tile commit; per workgroup:
       // first global loads (HBM latency) + epilogue.  Overheads of one workgroup hide behind the
       // matrix work of the other `occ` resident ones (measured: occupancy is the dominant lever).
@@ -494,11 +517,11 @@ struct rib_handle {
   std::vector<WinoSet> wino_sets;
   std::map<std::pair<int, int>, int> wino_index;
   bool weights_ready = false;
-  bool compute_bf16 = false;   // rib_set_compute_dtype: bf16 storage + bf16 matrix cores
-  int prec() const { return compute_bf16 ? PREC_BF16 : PREC_F32; }
-  bool mc16() const { return compute_bf16; }                             // the matrix-core kernels read bf16 filter copies, 16-channel steps
+  int prec_mode = PREC_F32;    // rib_set_compute_dtype: PREC_BF16 / PREC_F16 = 16-bit storage + 16-bit matrix-core operands
+  int prec() const { return prec_mode; }
+  bool mc16() const { return prec_mode != PREC_F32; }                    // the matrix-core kernels read 16-bit filter copies, 16-channel steps
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
-  int esz() const { return compute_bf16 ? 2 : 4; }                       // bytes per stored activation element
+  int esz() const { return mc16() ? 2 : 4; }                       // bytes per stored activation element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   std::map<uint64_t, std::unique_ptr<Plan>> plans;
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
@@ -615,20 +638,16 @@ void free_wino_sets(rib_handle* h) {
 static bool lowc_instantiated(int ce, int ncol) {
   return (ce == 6 && ncol == 64) || (ce == 10 && ncol == 32) || (ce == 22 && ncol == 32) || (ce == 24 && ncol == 16);
 }
-template <int CE, int NCOL> static void launch_lowc_t(bool bf16, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
-  if (tw == 16) {
-    if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false, 16>), grid, dim3(256), 0, st, p);
-  } else {
-    if (bf16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, true, 32>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, false, 32>), grid, dim3(256), 0, st, p);
-  }
+// (fp32 storage only: the 16-bit modes pack their inputs and run the first layers on the 16-bit matrix cores)
+template <int CE, int NCOL> static void launch_lowc_t(int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (tw == 16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, ST_F32, 16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, ST_F32, 32>), grid, dim3(256), 0, st, p);
 }
-static void launch_lowc(int ce, int ncol, bool bf16, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
-  if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(bf16, tw, grid, st, p);
-  else if (ce == 10 && ncol == 32) launch_lowc_t<10, 32>(bf16, tw, grid, st, p);
-  else if (ce == 22 && ncol == 32) launch_lowc_t<22, 32>(bf16, tw, grid, st, p);
-  else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(bf16, tw, grid, st, p);
+static void launch_lowc(int ce, int ncol, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
+  if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(tw, grid, st, p);
+  else if (ce == 10 && ncol == 32) launch_lowc_t<10, 32>(tw, grid, st, p);
+  else if (ce == 22 && ncol == 32) launch_lowc_t<22, 32>(tw, grid, st, p);
+  else if (ce == 24 && ncol == 16) launch_lowc_t<24, 16>(tw, grid, st, p);
 }
 
 // The blob starts with a header the importer checks (rib_import_weights): a blob is only meaningful to a handle with
@@ -713,7 +732,7 @@ void assign_weight_layout(rib_handle* h) {
   // with bf16 storage: there the packed bf16 copy + bf16 matrix cores are faster (679 vs 672 frames/s, A/B)
   for (auto& c : h->convs) {
     c.wl_off = 0; c.lowc_ce = c.lowc_ncol = 0;
-    if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || h->compute_bf16 || getenv("RIB_NO_LOWC")) continue;
+    if (!c.used || c.ks != 3 || c.stride != 1 || c.ups_in || c.fb_off != 0 || c.cin > 24 || h->mc16() || getenv("RIB_NO_LOWC")) continue;
     const int ncol = c.cout <= 16 ? 16 : c.coutp;      // (coutp is a multiple of 32; the 16-column instantiation serves Cout <= 16)
     const int ce = ncol == 16 ? (c.cin + 3) / 4 * 4 : (c.cin + 1) / 2 * 2;
     if (!lowc_instantiated(ce, ncol)) continue;
@@ -1898,17 +1917,31 @@ struct Resolver {
   }
 };
 
-template <int CO, int CIN> void launch_head_t(bool bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
-  if (bf16) hipLaunchKernelGGL((k_conv_head<CO, CIN, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_head<CO, CIN, false>), grid, dim3(256), 0, st, p);
+// a kernel templated on the storage type alone, launched for the handle's precision mode
+#define RIB_LAUNCH_ST(prec, KERNEL, grid, block, lds, st, ...)                                                        \
+  do {                                                                                                                \
+    if ((prec) == PREC_BF16) hipLaunchKernelGGL((KERNEL<ST_BF16>), grid, block, lds, st, __VA_ARGS__);                \
+    else if ((prec) == PREC_F16) hipLaunchKernelGGL((KERNEL<ST_F16>), grid, block, lds, st, __VA_ARGS__);             \
+    else hipLaunchKernelGGL((KERNEL<ST_F32>), grid, block, lds, st, __VA_ARGS__);                                     \
+  } while (0)
+
+template <int CO, int CIN> void launch_head_t(int bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
+  if (bf16 == PREC_BF16) hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_BF16>), grid, dim3(256), 0, st, p);
+  else if (bf16 == PREC_F16) hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_F16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_F32>), grid, dim3(256), 0, st, p);
 }
-void launch_head(int co, int cin, bool bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
+template <int CO> void launch_small_t(int bf16, dim3 grid, size_t lds, hipStream_t st, const IgemmParams& p) {
+  if (bf16 == PREC_BF16) hipLaunchKernelGGL((k_conv_small<CO, ST_BF16>), grid, dim3(256), lds, st, p);
+  else if (bf16 == PREC_F16) hipLaunchKernelGGL((k_conv_small<CO, ST_F16>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_conv_small<CO, ST_F32>), grid, dim3(256), lds, st, p);
+}
+void launch_head(int co, int cin, int bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
   if (cin == 16) { if (co == 1) launch_head_t<1, 16>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 16>(bf16, grid, st, p); else launch_head_t<3, 16>(bf16, grid, st, p); }
   else { if (co == 1) launch_head_t<1, 32>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 32>(bf16, grid, st, p); else launch_head_t<3, 32>(bf16, grid, st, p); }
 }
 
 int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool skip_label_ops = false) {
-  const bool bf16 = h->compute_bf16;
+  const int bf16 = h->prec();       // storage type of the activations: PREC_F32 / PREC_BF16 / PREC_F16
   for (Op& op : P->ops) {
     if (skip_label_ops && op.label_only) continue;     // done for the whole chain by the labels-only plan
     if (h->profiling) {      // one event in front of every launch (rib.h: a launch is charged the time to the next event)
@@ -1936,16 +1969,11 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
           launch_head(op.small_co, p.Cin, bf16, op.grid, st, p);
         } else if (op.small_co > 0) {
           const size_t lds = ((size_t)18 * 18 * (p.Cin + 4) + (size_t)op.small_co * 9 * p.Cin) * sizeof(float);
-          if (bf16) switch (op.small_co) {
-            case 1: hipLaunchKernelGGL((k_conv_small<1, true>), op.grid, dim3(256), lds, st, p); break;
-            case 2: hipLaunchKernelGGL((k_conv_small<2, true>), op.grid, dim3(256), lds, st, p); break;
-            case 3: hipLaunchKernelGGL((k_conv_small<3, true>), op.grid, dim3(256), lds, st, p); break;
-            default: hipLaunchKernelGGL((k_conv_small<4, true>), op.grid, dim3(256), lds, st, p); break;
-          } else switch (op.small_co) {
-            case 1: hipLaunchKernelGGL(k_conv_small<1>, op.grid, dim3(256), lds, st, p); break;
-            case 2: hipLaunchKernelGGL(k_conv_small<2>, op.grid, dim3(256), lds, st, p); break;
-            case 3: hipLaunchKernelGGL(k_conv_small<3>, op.grid, dim3(256), lds, st, p); break;
-            default: hipLaunchKernelGGL(k_conv_small<4>, op.grid, dim3(256), lds, st, p); break;
+          switch (op.small_co) {
+            case 1: launch_small_t<1>(bf16, op.grid, lds, st, p); break;
+            case 2: launch_small_t<2>(bf16, op.grid, lds, st, p); break;
+            case 3: launch_small_t<3>(bf16, op.grid, lds, st, p); break;
+            default: launch_small_t<4>(bf16, op.grid, lds, st, p); break;
           }
         } else
         hipLaunchKernelGGL(pick_igemm_fn(op.var, p), op.grid, dim3(256 * op.var->KW), 0, st, p);
@@ -1962,21 +1990,18 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.m_scale = R.get<const float>(op.m_sc); p.m_shift = R.get<const float>(op.m_sh);
         p.st.part = R.get<const double>(op.st_part[0]); p.st.gamma = R.get<const float>(op.st_gamma[0]); p.st.beta = R.get<const float>(op.st_beta[0]);
         p.ys0 = R.get<float>(op.m_ys0); p.ys1 = R.get<float>(op.m_ys1);
-        if (bf16) hipLaunchKernelGGL(k_spade_modulate<true>, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_spade_modulate<false>, op.grid, dim3(256), 0, st, p);
+        RIB_LAUNCH_ST(bf16, k_spade_modulate, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_SPLITEPI: {
         SplitEpiParams p = op.sp;
         p.slab = R.get<const float>(op.s_slab); p.bias = R.get<const float>(op.s_bias); p.y = R.get<float>(op.s_y);
         p.res = R.get<const float>(op.s_res); p.stat_part = R.get<double>(op.s_stat);
-        if (bf16) hipLaunchKernelGGL(k_splitk_epilogue<true>, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_splitk_epilogue<false>, op.grid, dim3(256), 0, st, p);
+        RIB_LAUNCH_ST(bf16, k_splitk_epilogue, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_POOL: {
         PoolParams p = op.pp;
         p.x = R.get<const float>(op.p_x); p.y = R.get<float>(op.p_y); p.stat_part = R.get<double>(op.p_stat);
-        if (bf16) hipLaunchKernelGGL(k_avgpool<true>, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_avgpool<false>, op.grid, dim3(256), 0, st, p);
+        RIB_LAUNCH_ST(bf16, k_avgpool, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_INADD: {
         InAddParams p = op.ap;
@@ -1985,8 +2010,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.xres = R.get<const float>(op.a_x); p.out = R.get<float>(op.a_out);
         p.st1.part = R.get<const double>(op.st_part[0]); p.st1.gamma = R.get<const float>(op.st_gamma[0]); p.st1.beta = R.get<const float>(op.st_beta[0]);
         p.sts.part = R.get<const double>(op.st_part[1]); p.sts.gamma = R.get<const float>(op.st_gamma[1]); p.sts.beta = R.get<const float>(op.st_beta[1]);
-        if (bf16) hipLaunchKernelGGL(k_in_add<true>, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_in_add<false>, op.grid, dim3(256), 0, st, p);
+        RIB_LAUNCH_ST(bf16, k_in_add, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_WINO_IN: {
         WinoInParams p = op.wi;
@@ -2019,14 +2043,13 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.s0 = R.get<const float>(op.lc_s0); p.s1 = R.get<const float>(op.lc_s1); p.s2 = R.get<const float>(op.lc_s2);
         p.w = R.get<const float>(op.lc_w); p.bias = R.get<const float>(op.lc_bias); p.y = R.get<float>(op.lc_y);
         p.stat_part = R.get<double>(op.lc_stat);
-        launch_lowc(op.lowc_ce, op.lowc_ncol, bf16, op.lowc_tw, op.grid, st, p);
+        launch_lowc(op.lowc_ce, op.lowc_ncol, op.lowc_tw, op.grid, st, p);
       } break;
       case OP_PACK: {
         PackParams p = op.kp;
         p.s0 = R.get<const float>(op.k_s0); p.s1 = R.get<const float>(op.k_s1); p.s2 = R.get<const float>(op.k_s2);
         p.dst = R.get<float>(op.k_dst);
-        if (bf16) hipLaunchKernelGGL(k_pack<true>, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_pack<false>, op.grid, dim3(256), 0, st, p);
+        RIB_LAUNCH_ST(bf16, k_pack, op.grid, dim3(256), 0, st, p);
       } break;
     }
   }
@@ -2244,7 +2267,8 @@ int rib_finalize_weights(rib_handle* h) {
     // rows of `rowlen` K-contiguous elements: [row][rowlen] bf16
     auto to16 = [&](size_t src, size_t dst, size_t rows, size_t rowlen) {
       uint16_t* d = reinterpret_cast<uint16_t*>(&blob[dst]);
-      for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_bf16(blob[src + i]);
+      if (h->prec() == PREC_F16) for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_f16(blob[src + i]);
+      else for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_bf16(blob[src + i]);
     };
     for (auto& c : h->convs) {
       if (!c.used) continue;
@@ -2314,8 +2338,9 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
 }
 
 int rib_set_compute_dtype(rib_handle* h, int dtype) {
-  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16)) return RIB_ERR_INVALID;
-  if (h->compute_bf16 == (dtype == RIB_DTYPE_BF16)) return RIB_OK;
+  if (!h || (dtype != RIB_DTYPE_F32 && dtype != RIB_DTYPE_BF16 && dtype != RIB_DTYPE_F16)) return RIB_ERR_INVALID;
+  const int mode = dtype == RIB_DTYPE_BF16 ? PREC_BF16 : (dtype == RIB_DTYPE_F16 ? PREC_F16 : PREC_F32);
+  if (h->prec_mode == mode) return RIB_OK;
   // The storage type decides the activation / filter layout (bf16: 16-channel minimum, bf16 filter copies in the
   // blob): plans and the weight layout are rebuilt, and the folded blob has to be produced again - by
   // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
@@ -2323,7 +2348,7 @@ int rib_set_compute_dtype(rib_handle* h, int dtype) {
   h->plans.clear();
   free_wino_sets(h);       // (plans reference them by index; the bf16 mode has none)
   h->choices.clear();      // tuned variant indices belong to the previous precision's kernels: back to the cost model until re-pinned
-  h->compute_bf16 = dtype == RIB_DTYPE_BF16;
+  h->prec_mode = mode;
   assign_weight_layout(h);
   const bool had = h->weights_ready || !h->host_blob.empty();
   h->weights_ready = false;
@@ -2404,11 +2429,7 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
   const int tilesX = (W + WARP_T - 1) / WARP_T, tilesY = (H + WARP_T - 1) / WARP_T;
-  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);      // 9.4 KB per channel
-  if (lds > 48 * 1024) {      // beyond the default dynamic-LDS limit (C >= 6): raise it once
-    static bool raised = false;
-    if (!raised) { HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_warp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WARP_WIN * (WARP_WIN + 1) * (int)sizeof(float))); raised = true; }
-  }
+  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);
   hipLaunchKernelGGL(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
@@ -2606,8 +2627,7 @@ int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* worksp
   const Tap& t = P->taps[idx];
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + t.off);
-  if (h->compute_bf16) hipLaunchKernelGGL(k_unpack<true>, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
-  else hipLaunchKernelGGL(k_unpack<false>, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
+  RIB_LAUNCH_ST(h->prec(), k_unpack, dim3((t.H * t.W + 255) / 256, B), dim3(256), 0, st, src, t.Cp, t.C, t.H * t.W, 0, t.H, t.W, dst);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(st));
   return RIB_OK;
@@ -2687,7 +2707,7 @@ int rib_variant_info(int idx, int geom[12]) {
   const Variant& v = kVariants[idx];
   const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.TB};
   for (int i = 0; i < 12; ++i) geom[i] = g[i];
-  return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage
+  return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage, 2 half storage
 }
 
 int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int variant_idx, int ksplit) {

@@ -6,7 +6,7 @@
 // rib.hip's RIB_V / RIB_VK / ... table macros name the same instantiations; keep the two in step.
 #pragma once
 
-// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (false / true = 0 / 1), AUX, PRO, KW, TB
+// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (0 fp32 / 1 bf16 / 2 half; false = 0), AUX, PRO, KW, TB
 #define RIB_F_EXTERN(...) extern template __global__ void rib::k_igemm<__VA_ARGS__>(const rib::IgemmParams);
 #define RIB_F_TOUCH(...) &rib::k_igemm<__VA_ARGS__>,
 
@@ -38,13 +38,14 @@
 #define RIB_I_VU4(F, FRW, WM, WN, MF, NF, BK)                                             \
   F(FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, true, 1, 4)                 \
   F(FRW, WM, WN, MF, NF, BK, 1, 3, true, false, false, false, false, 1, 4)
-// SPADE geometry / its in-workgroup split-K twin / bf16 matrix-core twin
+// SPADE geometry / its in-workgroup split-K twin / 16-bit matrix-core twins (bf16 and half)
 #define RIB_I_VS(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, false)
 #define RIB_I_VSK(F, FRW, WM, WN, MF, NF, BK, KW) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, false, true, true, KW)
-#define RIB_I_VB(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true)
+#define RIB_I_VB(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 1) F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2)
 // bf16-storage variant with explicit wave groups / slices per barrier (one instantiation: shortcut loop where it can exist, prologue)
 #define RIB_I_VBX(F, FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, KW, TB) \
-  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, true, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 1, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB) \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB)
 // 1x1 with input tile and filter slice double-buffered (TB = 2: one barrier per chunk), optional wave groups; conv (generic = pro, lean) and SPADE
 #define RIB_I_V1D(F, FRW, WM, WN, MF, NF, BK, KW)                                \
   F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2)          \

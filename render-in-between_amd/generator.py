@@ -29,10 +29,11 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class Generator:
     def __init__(self, gen_cfg, device=None, use_tuning=True, compute_dtype="f32"):
-        """compute_dtype: 'f32' (exact-fp32 matrix cores; the reference's arithmetic) or 'bf16'
-        (bf16 matrix-core operands, fp32 accumulate / statistics / storage; BASELINE config 3)."""
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        """compute_dtype: 'f32' (exact-fp32 matrix cores; the reference's arithmetic), 'bf16' (bf16 storage and
+        matrix-core operands, fp32 accumulate / statistics; BASELINE config 3) or 'f16' (the same 16-bit kernels
+        with IEEE half elements: ~10x closer to fp32 than bf16 at the same speed)."""
+        if compute_dtype not in ("f32", "bf16", "f16"):
+            raise ValueError("compute_dtype must be 'f32', 'bf16' or 'f16'")
         self.compute_dtype = compute_dtype
         self.spec = GenSpec.from_cfg(gen_cfg)
         self._tuning = None
@@ -64,7 +65,7 @@ class Generator:
             raise (NotImplementedError if rc == -2 else _native.RibError)(
                 *(("rib_create: " + msg.decode(),) if rc == -2 else (rc, msg.decode())))
         self._h = h
-        _native.check(h, self._lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1}[compute_dtype]))
+        _native.check(h, self._lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1, "f16": 3}[compute_dtype]))
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.training = False
         self.weights_version = 0        # bumped by load_state_dict / import_weights (Evaluator's lane clones follow it)

@@ -95,8 +95,8 @@ if __name__ == "__main__":
     parser.add_argument("--save-dir", type=str, default="../example", help="outputs path")
     parser.add_argument("--input-dir", type=str, required=True, help="input low FPS frames and pose input")
     parser.add_argument("--seed", type=int, default=123)
-    parser.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                        help="f32: the reference's arithmetic (default); bf16: bf16 storage, ~2x the frame rate, ~1e-2 mean deviation "
+    parser.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32",
+                        help="f32: the reference's arithmetic (default); bf16 / f16: 16-bit storage, ~2x the frame rate, ~1e-2 / ~1e-3 mean deviation "
                              "(not in the reference: it is fp32 only)")
     parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")
     main(parser.parse_args())

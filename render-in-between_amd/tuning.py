@@ -11,8 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TUNING_PATH = os.path.join(_HERE, "tuning_gfx950.json")
 # one table per precision mode, each measured on that mode's own kernels (tools/autotune.py --dtype ...)
-TUNING_PATHS = {"f32": TUNING_PATH, "bf16": os.path.join(_HERE, "tuning_gfx950_bf16.json")}
-PREC = {"f32": 0, "bf16": 1}           # what rib_variant_info returns for a variant of that mode
+# (the half mode runs the bf16 mode's kernels with another element type: same geometries, same table)
+TUNING_PATHS = {"f32": TUNING_PATH, "bf16": os.path.join(_HERE, "tuning_gfx950_bf16.json"), "f16": os.path.join(_HERE, "tuning_gfx950_bf16.json")}
+PREC = {"f32": 0, "bf16": 1, "f16": 2}           # what rib_variant_info returns for a variant of that mode
 
 
 def load(path=None, dtype="f32"):

@@ -156,7 +156,7 @@ def test_precision_mode_switch_refolds_the_weights(lib):
     assert lib.rib_finalize_weights(h) == 0
     n32 = lib.rib_weights_bytes(h)
     sizes = {}
-    for mode in (1, 0):
+    for mode in (1, 3, 0):       # bf16, half, fp32
         assert lib.rib_set_compute_dtype(h, mode) == 0, lib.rib_last_error(h)
         sizes[mode] = lib.rib_weights_bytes(h)
         for cname in ("ref_embedding.conv_first", "down_1.conv_block_0", "conv_img"):
@@ -167,7 +167,7 @@ def test_precision_mode_switch_refolds_the_weights(lib):
         for (B, H, W) in ((1, 64, 64), (2, 48, 80), (1, 16, 16)):
             assert lib.rib_workspace_bytes(h, B, H, W) > 0, (mode, lib.rib_last_error(h))
     # (fp32 carries the Winograd-domain filters of the deep 3x3 layers; bf16 carries bf16 copies instead)
-    assert sizes[0] == n32 and sizes[1] != n32
+    assert sizes[0] == n32 and sizes[1] != n32 and sizes[3] == sizes[1]          # (the two 16-bit modes share a layout)
     assert lib.rib_set_compute_dtype(h, 7) != 0 and lib.rib_set_compute_dtype(h, 2) != 0      # (2 was round 2's retired f32x3 mode)
     lib.rib_destroy(h)
 
@@ -237,7 +237,7 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
             assert int(ch[10]) >= 1
     assert not stale, stale[:5]
     # the bf16-storage mode has a table of its own, measured on its own kernels
-    for dtype in ("bf16",):
+    for dtype in ("bf16", "f16"):          # (half runs the bf16 geometries with another element type: same table)
         geoms = set()
         for i in range(lib.rib_num_variants()):
             if lib.rib_variant_info(i, g12) == tuning.PREC[dtype]:

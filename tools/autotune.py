@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="precision mode whose kernels are measured")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32", help="precision mode whose kernels are measured")
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--report", type=str, default=None)
     ap.add_argument("--only", type=str, default=None,
