@@ -1204,6 +1204,114 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
 
 #ifndef RIB_IGEMM_ONLY   // igemm_shard.hip compiles k_igemm only; everything below is instantiated by rib.hip
 // ---------------------------------------------------------------------------------------------
+// k_gemm_dma (round 3): the plain GEMMs of the frame - the 16 / 36 batched Winograd-domain GEMMs of a deep 3x3 layer and
+// the gamma/beta GEMM of a condition level - with their operand tiles staged by LDS-DMA.
+//   C[z][M][N] = sum_k A[z][M][K] * B[z % modB][N][K]      fp32, v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 sums)
+// A rows are pixels / Winograd tiles with K = channels contiguous (row stride lda), B rows are output channels with K
+// contiguous (the filter layouts of the blob and of the Winograd sets as they are).
+// k_igemm stages its tiles global -> registers -> LDS (ds_write_b128) and double-buffers through registers; here every
+// wave issues global_load_lds_dwordx4 (gfx950: 16 bytes per lane straight into LDS, no staging registers, no ds_write):
+// one instruction lands 64 consecutive 16-byte slots = 8 rows of a 32-float K chunk, so rows cannot be padded against bank
+// conflicts; the slot of a row is XOR-swizzled instead (slot' = slot ^ ((row >> 1) & 7): conflict-free for the lane groups
+// of ds_read_b128).  Two LDS stages; per chunk: s_waitcnt vmcnt(0), one barrier, the fills of the next chunk, then the MFMAs
+// of this one run over them.  tools/probes/ldsdma_probe.hip, same process, same problems: 74.9 vs 90.8 us on the level GEMM
+// (115 vs 95 TFLOP/s), 22.4 vs 36.7 us on the 16-position 512-channel GEMM, 279 vs 306 us on a 34 GFLOP launch; a
+// four-stage ring was slower than two stages (LDS: fewer workgroups per CU).
+// The DMA instruction is inline assembly on purpose: the compiler's wait-count pass cannot tell LDS stages apart and puts
+// s_waitcnt vmcnt(0) in front of every ds_read that follows a builtin fill - the prefetch would never overlap anything.
+// Rows beyond M / N are clamped on the load side (valid addresses, values unused) and skipped on the store side; K is a
+// multiple of 32.  Workgroup = 4 waves as WM x WN; a wave owns 32 rows x (32 NF) columns; tile (32 WM) x (32 NF WN).
+// grid (ceil(M / BM), ceil(N / BN), Z).
+// ---------------------------------------------------------------------------------------------
+struct GemmDmaParams {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldc;
+  size_t sA, sB, sC;      // element strides of the batch index z (B: of z % modB)
+  int modB;               // 0: one B for every z
+};
+
+template <int WM, int WN, int NF>
+__global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = 32 * WM, BN = 32 * NF * WN, BK = 32;
+  constexpr int STAGE = (BM + BN) * BK;              // floats
+  constexpr int NFILL = (BM + BN) / 32;              // DMA instructions per wave and chunk (8 rows each)
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const float* A = p.A + (size_t)z * p.sA;
+  const float* B = p.B + (size_t)(p.modB ? z % p.modB : 0) * p.sB;
+  f32x16 acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+  const int nch = p.K / BK;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  // this lane's source rows: fill j of a wave covers tile rows [wave * 8 + 32 j, + 8) of the stacked (A rows | B rows) tile;
+  // lane -> row lane / 8, physical slot lane % 8 = logical slot ^ ((row >> 1) & 7)
+  const float* src[NFILL];
+#pragma unroll
+  for (int j = 0; j < NFILL; ++j) {
+    const int trow = wave * 8 + 32 * j + (lane >> 3);                 // row of the stacked tile
+    const bool isA = 32 * j < BM;                                     // (BM is a multiple of 32: a fill never straddles A | B)
+    const int row = isA ? trow : trow - BM;
+    const int ls = (lane & 7) ^ ((row >> 1) & 7);
+    src[j] = isA ? A + (size_t)min(m0 + row, p.M - 1) * p.lda + ls * 4 : B + (size_t)min(n0 + row, p.N - 1) * p.K + ls * 4;
+  }
+  auto fill = [&](int st, int kc) {
+#pragma unroll
+    for (int j = 0; j < NFILL; ++j) {
+      const uint32_t dst = lds0 + (uint32_t)(st * STAGE + (wave * 8 + 32 * j) * BK) * 4u;      // wave-uniform byte address
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src[j] + kc) : "memory");
+    }
+  };
+  fill(0, 0);
+  for (int c = 0; c < nch; ++c) {
+    const int st = c & 1;
+    // chunk c has landed (this wave's part; the barrier collects the others') and everybody is done with chunk c - 1
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 1 < nch) fill(st ^ 1, (c + 1) * BK);
+    const float* sA = smem + st * STAGE;
+    const float* sB = sA + BM * BK;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const int slot = kb * 2 + lh;
+      const int ra = wm * 32 + li;
+      const float4 a = *reinterpret_cast<const float4*>(sA + ra * BK + (slot ^ ((ra >> 1) & 7)) * 4);
+      float4 b[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int rb = (wn * NF + nf) * 32 + li;
+        b[nf] = *reinterpret_cast<const float4*>(sB + rb * BK + (slot ^ ((rb >> 1) & 7)) * 4);
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nf].x, acc[nf], 0, 0, 0);
+        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nf].y, acc[nf], 0, 0, 0);
+        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nf].z, acc[nf], 0, 0, 0);
+        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nf].w, acc[nf], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator element r of lane l: row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
+  float* C = p.C + (size_t)z * p.sC;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int col = n0 + (wn * NF + nf) * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < p.M && col < p.N) C[(size_t)row * p.ldc + col] = acc[nf][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_stats_finalize: per-tile partial sums -> (scale, shift) of the InstanceNorm that follows.
 //   mean = S1/N, var = S2/N - mean^2 (biased), rstd = 1/sqrt(var+eps)
 //   scale = rstd*gamma, shift = beta - mean*scale   (gamma=1, beta=0 when affine is absent)

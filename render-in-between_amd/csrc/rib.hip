@@ -233,10 +233,17 @@ struct Variant {
   IgemmFn fn_lean = nullptr;   // without the fused-shortcut loop and without the prologue
   int KW = 1;                  // in-workgroup split-K: KW groups of 4 waves (256*KW threads) per tile
   int TB = 1;                  // filter slices staged per barrier: 1 tap, or 3 = one row of a 3x3 filter
+  // FRW == 0: not a k_igemm instantiation but a tile of k_gemm_dma (plain GEMM, operands staged by LDS-DMA): (32 WM) x (32 NF WN),
+  // fp32 only; serves the batched Winograd-domain GEMMs and the condition-level gamma/beta GEMM
+  typedef void (*GemmDmaFn)(const GemmDmaParams);
+  GemmDmaFn gfn = nullptr;
+  bool dma() const { return FRW == 0; }
+  int BM() const { return 32 * WM; }
   int TH() const { return (32 / FRW) * MF * WM; }
   int TW() const { return FRW; }
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
+    if (dma()) return 2 * (BM() + BN()) * 32 * 4;
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
     const int ck = (BF16 != PREC_F32 ? BK / 2 : BK) + 4;   // IgemmGeom::CK
@@ -315,8 +322,16 @@ inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
   return v->fn_pro ? v->fn_pro : v->fn;
 }
 
+inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn) {
+  Variant v{0, WM, WN, 1, NF, 32, 1, 1, false, false, nullptr};
+  v.gfn = fn;
+  return v;
+}
 const Variant kVariants[] = {
 #include "variants.def"
+    // k_gemm_dma tiles (instantiated in this translation unit): 128x64, 64x64, 64x128, 128x128, 128x32
+    dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2>), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1>), dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2>),
+    dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4>), dma_variant(4, 1, 1, &k_gemm_dma<4, 1, 1>),
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -343,6 +358,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
+    if (v.dma()) continue;                  // (chosen by pick_gemm_dma)
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     if (v.NF == 0 && !allow_n16) continue;
     if (v.SPADE && v.NF == 1) continue;      // 16-channel SPADE layout: chosen explicitly (Builder::spade)
@@ -380,10 +396,27 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
   return best;
 }
 
+// default k_gemm_dma tile of a Z x [M x N x K] problem: the largest tile that still gives two workgroups per CU, else the
+// tile with the most workgroups (RIB_NO_DMA=1: none - the callers fall back to k_igemm's 1x1 variants)
+const Variant* pick_gemm_dma(int prec, long Z, int M, int N) {
+  static const bool off = getenv("RIB_NO_DMA") != nullptr;
+  if (off || prec != PREC_F32) return nullptr;
+  const Variant* best = nullptr; long best_area = 0, best_wgs = 0;
+  for (int i = 0; i < kNumVariants; ++i) {
+    const Variant& v = kVariants[i];
+    if (!v.dma()) continue;
+    const long wgs = Z * ((M + v.BM() - 1) / v.BM()) * ((N + v.BN() - 1) / v.BN());
+    const long area = (long)v.BM() * v.BN();
+    const bool full = wgs >= 512, bfull = best_wgs >= 512;
+    if (!best || (full && (!bfull || area > best_area)) || (!full && !bfull && wgs > best_wgs)) { best = &v; best_area = area; best_wgs = wgs; }
+  }
+  return best;
+}
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
-enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE, OP_WINO_IN, OP_WINO_OUT, OP_LOWC };
+enum OpKind { OP_PACK, OP_IGEMM, OP_FINALIZE, OP_POOL, OP_INADD, OP_SPLITEPI, OP_MODULATE, OP_WINO_IN, OP_WINO_OUT, OP_LOWC, OP_GEMM };
 
 // pointer encoding inside a plan: workspace-relative offsets (bytes) or weight-blob offsets
 // (floats); resolved at launch time.
@@ -433,6 +466,7 @@ struct Op {
   // Winograd transforms
   WinoInParams wi; PRef wi_x, wi_sc, wi_sh, wi_v, wi_slab, wi_sbias, wi_x2, wi_xres, wi_o, wi_sc2, wi_sh2; int wi_mode = 0;
   WinoOutParams wo; PRef wo_m, wo_bias, wo_y, wo_res, wo_stat;
+  GemmDmaParams gp; PRef g_a, g_b, g_c;      // OP_GEMM: k_gemm_dma (tile = var)
   bool wino = false;   // this k_igemm launch is the 16- / 36-way batched Winograd-domain GEMM (executes 4/9 or 1/4 of its nine-tap FLOP count)
   int wino_m = 0;      // 2 or 4 on the three launches of a Winograd convolution
 };
@@ -979,7 +1013,7 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        const bool ok = tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+        const bool ok = !tv.dma() && tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
                         (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
@@ -1200,7 +1234,10 @@ struct Builder {
       push(op);
     }
     {   // the 16 / 36 GEMMs as one 1x1 "convolution" of NP*B samples of a tilesY x tilesX image, one filter set per position
-      Choice ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * NP, tilesY, tilesX, c.cinp, false, 0, false);
+      // k_gemm_dma (operands staged by LDS-DMA) unless a tuned choice names a k_igemm 1x1 variant; TB_() decides as for every choice
+      Choice ch;
+      ch.v = pick_gemm_dma(h->prec(), (long)TB_() * NP, ntiles, c.coutp);
+      if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * NP, tilesY, tilesX, c.cinp, false, 0, false);
       auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, gname.c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
@@ -1211,20 +1248,33 @@ struct Builder {
       }
       const Variant* v = ch.v;
       if (!v) { error = gname + ": no 1x1 kernel variant"; return false; }
+      const int set = ensure_wino_set(h, (int)(&c - h->convs.data()), wm);
+      if (set < 0) { error = gname + ": " + h->err; return false; }
       Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_IGEMM; op.name = gname; op.var = v; op.wino = true; op.wino_m = wm;
+      op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 or 1/4 of it)
+      if (v->dma()) {
+        // M[n*NP + xi] = V[n*NP + xi] . U[xi]^T: Z = B*NP problems of ntiles x coutp x cinp
+        op.kind = OP_GEMM;
+        GemmDmaParams& g = op.gp;
+        memset(&g, 0, sizeof g);
+        g.M = ntiles; g.N = c.coutp; g.K = c.cinp; g.lda = c.cinp; g.ldc = c.coutp;
+        g.sA = (size_t)ntiles * c.cinp; g.sB = (size_t)c.coutp * c.cinp; g.sC = (size_t)ntiles * c.coutp; g.modB = NP;
+        op.g_a = WS(v_off); op.g_b = PRef(); op.g_b.sp = PS_WINO; op.g_b.off = (size_t)set; op.g_c = WS(m_off);
+        op.grid = dim3((ntiles + v->BM() - 1) / v->BM(), (c.coutp + v->BN() - 1) / v->BN(), B * NP);
+        P->flops[RIB_KC_IGEMM] += op.flops;
+        push(op);
+      } else {
       IgemmParams& p = op.ip;
       memset(&p, 0, sizeof p);
       p.Hin = tilesY; p.Win = tilesX; p.xC = c.cinp; p.Cin = c.cinp; p.CoutPad = c.coutp; p.Hout = tilesY; p.Wout = tilesX;
       p.tilesX = (tilesX + v->TW() - 1) / v->TW(); p.tilesY = (tilesY + v->TH() - 1) / v->TH(); p.xcd_chunk = xcd_chunk_of(p.tilesX * p.tilesY);
       p.act = ACT_NONE; p.ksplit = 1; p.yC = c.coutp; p.yoff = 0; p.Cout = c.coutp;
       p.w_mod = NP; p.w_stride = (unsigned)((size_t)c.coutp * c.cinp);
-      const int set = ensure_wino_set(h, (int)(&c - h->convs.data()), wm);
-      if (set < 0) { error = gname + ": " + h->err; return false; }
       op.x = WS(v_off); op.w = PRef(); op.w.sp = PS_WINO; op.w.off = (size_t)set; op.bias = WT(c.zero_off); op.y = WS(m_off);
       op.grid = dim3(p.tilesX * p.tilesY, (c.coutp + v->BN() - 1) / v->BN(), B * NP);
-      op.flops = 2.0 * c.cin * 9.0 * c.cout * (double)Hout * Wout * B;      // the convolution's algorithmic count (executed: 4/9 or 1/4 of it)
       P->flops[RIB_KC_IGEMM] += op.flops;
       push(op);
+      }
     }
     {   // output transform + the convolution's epilogue
       Op op; op.kind = OP_WINO_OUT; op.kclass = RIB_KC_CONVAUX; op.name = opname + ".wino_out"; op.for_op = gname; op.wino_m = wm;
@@ -1279,7 +1329,9 @@ struct Builder {
     }
     const SpadeGroup& first = h->spades[it->second[0]];
     const std::string name = fmt("cond_%d.gammabeta", level);
-    Choice ch = choose_variant(h->prec(), 1, 1, false, false, N, B, cond.H, cond.W, cond.Cp, false);
+    Choice ch;
+    ch.v = pick_gemm_dma(h->prec(), B, cond.H * cond.W, N);
+    if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, N, B, cond.H, cond.W, cond.Cp, false);
     {
       auto ct = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, name.c_str()));
       if (ct != h->choices.end()) {
@@ -1294,6 +1346,22 @@ struct Builder {
     if (!v) { error = name + ": no 1x1 kernel variant"; return false; }
     const size_t slab_off = alloc((size_t)B * cond.H * cond.W * N * sizeof(float));
     Op op; op.kind = OP_IGEMM; op.kclass = RIB_KC_SPADE; op.name = name; op.var = v;
+    op.flops = fl;
+    if (v->dma()) {
+      // slab[b] = cond[b] . W_level^T: B problems of (H*W) x N x Cp
+      op.kind = OP_GEMM;
+      GemmDmaParams& g = op.gp;
+      memset(&g, 0, sizeof g);
+      g.M = cond.H * cond.W; g.N = N; g.K = cond.Cp; g.lda = cond.Cp; g.ldc = N;
+      g.sA = (size_t)g.M * cond.Cp; g.sB = 0; g.sC = (size_t)g.M * N; g.modB = 0;
+      op.g_a = WS(cond.off); op.g_b = WT(first.w_off); op.g_c = WS(slab_off);
+      op.grid = dim3((g.M + v->BM() - 1) / v->BM(), (N + v->BN() - 1) / v->BN(), B);
+      P->flops[RIB_KC_SPADE] += fl;
+      push(op);
+      LevelSlab ls; ls.off = slab_off; ls.ld = N;
+      level_slab[level] = ls;
+      return true;
+    }
     IgemmParams& p = op.ip;
     memset(&p, 0, sizeof p);
     p.Hin = cond.H; p.Win = cond.W; p.xC = cond.Cp; p.Cin = cond.Cp;
@@ -1337,7 +1405,7 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1) ||
+        if (tv.dma() || tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || cond.Cp % tv.BK != 0 || ts < 1 || ts > cond.Cp / tv.BK || (tv.SPADE && ts != 1) ||
             (tv.SPADE && tv.NF == 1 && !sg.w1_off)) {
           error = key + ": tuned SPADE choice does not fit"; return false;
         }
@@ -1558,7 +1626,7 @@ struct Builder {
                    &op.m_ys0, &op.m_ys1, &op.f_part, &op.f_gamma, &op.f_beta, &op.f_scale, &op.f_shift, &op.p_x, &op.p_y, &op.p_stat,
                    &op.a_t1, &op.a_sc1, &op.a_sh1, &op.a_ts, &op.a_scs, &op.a_shs, &op.a_x, &op.a_out, &op.k_s0, &op.k_s1, &op.k_s2, &op.k_dst,
                    &op.wi_x, &op.wi_sc, &op.wi_sh, &op.wi_v, &op.wi_slab, &op.wi_x2, &op.wi_xres, &op.wi_o, &op.wi_sc2, &op.wi_sh2, &op.wo_m, &op.wo_bias, &op.wo_y, &op.wo_res, &op.wo_stat,
-                   &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat, &op.st_part[0], &op.st_part[1]};
+                   &op.lc_s0, &op.lc_s1, &op.lc_s2, &op.lc_w, &op.lc_bias, &op.lc_y, &op.lc_stat, &op.st_part[0], &op.st_part[1], &op.g_a, &op.g_c};
     for (PRef* r : all) if (r->sp == PS_WS) f(*r);
   }
   AllocRec* alloc_of(size_t voff) {
@@ -1977,6 +2045,11 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
           }
         } else
         hipLaunchKernelGGL(pick_igemm_fn(op.var, p), op.grid, dim3(256 * op.var->KW), 0, st, p);
+      } break;
+      case OP_GEMM: {
+        GemmDmaParams p = op.gp;
+        p.A = R.get<const float>(op.g_a); p.B = R.get<const float>(op.g_b); p.C = R.get<float>(op.g_c);
+        hipLaunchKernelGGL(op.var->gfn, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_FINALIZE: {
         FinalizeParams p = op.fp;
@@ -2690,6 +2763,9 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
              op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
+  else if (op.kind == OP_GEMM)
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|gemm (LDS-DMA staged operands) tile %dx%d BK 32, %d x [%d x %d x %d]%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+             op.var->BM(), op.var->BN(), (int)op.grid.z, op.gp.M, op.gp.N, op.gp.K, op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
   else if (op.kind == OP_LOWC)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|lowc (caller's NCHW tensors, K = 9 x %d real channels) 8x%d tile, %d columns|%.0f", op.name.c_str(), op.kclass,
              op.grid.x, op.grid.y, op.grid.z, op.lowc_ce, op.lowc_tw, op.lowc_ncol, op.flops);
