@@ -62,6 +62,8 @@
 #define RIB_VBX(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VBX(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_V1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_V1D(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VS1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VS1D(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VD(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VD(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VSD(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VSD(RIB_F_TOUCH, __VA_ARGS__))
 
 typedef void (*IgemmFn)(const rib::IgemmParams);
 extern "C" __attribute__((used, visibility("hidden"))) IgemmFn const RIB_CAT(rib_igemm_section_, RIB_SECTION)[] = {

@@ -174,6 +174,9 @@ struct IgemmParams {
   // image, y[b] at channel offsets yoff and yoff + pair_yoff (the torch.cat of generator.py:505); the statistics partials
   // stay per sample ---
   unsigned b_stride; int pair, pair_yoff;
+  // --- DMA instantiations (operand tiles staged by global_load_lds_dwordx4): 64 bytes of zeros in device memory, the
+  // source of the input tile's out-of-image (zero padding) pixels ---
+  const float* zeros;
 };
 
 enum { STATS_MAX_PARTIALS = 128 };
@@ -214,7 +217,12 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // fp32 storage, operands split into three bf16 terms, six bf16 MFMAs per step - never beat fp32 once the deep layers ran
 // in the Winograd domain and was retired in round 3.)
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };      // = ST_F32 / ST_BF16 / ST_F16
-template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, int PREC = 0>
+// DMA (round 3): bit 0 = the filter slices, bit 1 = the input tile are staged by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers, no ds_write) instead of global -> registers -> LDS.  A DMA instruction lands 64 consecutive 16-byte slots, so the
+// rows of a DMA-staged tile are NOT padded; the 16-byte slot of a row is XOR-swizzled instead (swz below), which is
+// conflict-free for the filter reads and nearly so for the shifted-window reads of the input tile.  The DMA-staged input
+// tile is double-buffered (the fill of chunk k + 1 lands while chunk k is being read).
+template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, int KW = 1, int TB = 1, int PREC = 0, int DMA = 0>
 struct IgemmGeom {
   static constexpr bool BF16 = PREC != PREC_F32;      // 16-bit storage (bf16 or half): the layouts only depend on the element size
   static constexpr int NT = 256 * KW;          // threads: KW groups of 4 waves share the tile and split each tap's K
@@ -242,13 +250,22 @@ struct IgemmGeom {
   // NF == 0 selects the 16-column path (v_mfma_f32_16x16x4_f32) for layers with <= 16 output
   // channels: no half-empty 32-column fragments
   static constexpr int BN = NF == 0 ? 16 * WN : 32 * NF * WN;
-  static constexpr int SA = IH * IWP * CK;     // floats
-  static constexpr int SB = BN * CK;           // floats, one of two buffers
+  static constexpr int AP = (DMA & 2) ? KF : CK;     // floats per pixel row of the input tile in LDS
+  static constexpr int BP = (DMA & 1) ? KF : CK;     // floats per filter row in LDS
+  static constexpr int SLOTS = KF / 4;               // 16-byte slots per row of a K chunk
+  static constexpr int SWZ_SHIFT = SLOTS >= 16 ? 0 : (SLOTS == 8 ? 1 : (SLOTS == 4 ? 2 : 3));
+  // physical slot of logical slot s in row r of a DMA-staged tile: the 16 lanes of a ds_read_b128 group (rows 0-3, 12-15,
+  // 20-27 / 4-11, 16-19, 28-31 of a fragment at one slot) then hit 16 different 4-bank groups
+  __device__ static constexpr int swz(int r, int s) { return s ^ ((r >> SWZ_SHIFT) & (SLOTS - 1)); }
+  static constexpr int NQA = (DMA & 2) ? (IH * IWP * SLOTS + 255) / 256 : 0;   // DMA instructions per wave for the input tile of a chunk
+  static constexpr int NQB = (DMA & 1) ? (BN * SLOTS + 255) / 256 : 0;         //                            for one filter slice
+  static constexpr int SA = (DMA & 2) ? NQA * 256 * 4 : IH * IWP * CK;         // floats (DMA: whole instructions)
+  static constexpr int SB = (DMA & 1) ? NQB * 256 * 4 : BN * CK;               // floats, one of two buffers
   static constexpr int NB4 = (BN * GPRB + NT - 1) / NT;    // 16-byte filter loads per thread per tap
   static constexpr int SRED = WM * BN * 4;     // floats: [WM][BN][2] fp64 statistics partials
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   // TB = 9 (3x3) and TB = 2 (1x1: "chunk pairs") also double-buffer the input tile: one barrier per chunk
-  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2)) ? 2 : 1;
+  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2) || (DMA & 2)) ? 2 : 1;
   static constexpr int TBB = (KS == 1 && TB == 2) ? 1 : TB;   // filter slices per buffer
   static constexpr int SMEM0 = NA * SA + 2 * TBB * SB > SRED ? NA * SA + 2 * TBB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
@@ -275,14 +292,16 @@ struct IgemmGeom {
 // SOURCE pixels and keeps four accumulator sets, one per phase; filter slice t = phase*4 + a*2 + b
 // multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, int PREC = 0,
-          bool AUX = true, bool PRO = true, int KW = 1, int TB = 1>
+          bool AUX = true, bool PRO = true, int KW = 1, int TB = 1, int DMA = 0>
 // Second launch bound = minimum waves per SIMD the register allocator must leave room for.  The fp32 variants with
 // two column fragments per wave (NF = 2: 32 accumulator registers) sit exactly on the 128-register boundary of 4 waves
 // per SIMD; one more live value in an epilogue made the allocator give up and settle at 3 (97 + 32 registers), which
 // cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
 // and fits 99-104 registers without spilling.
 __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
-  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC> G;
+  typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
+  static_assert(DMA == 0 || (PREC == PREC_F32 && TB == 1 && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)), "DMA staging: fp32, one slice per barrier, 32-column path, no fused shortcut");
+  static_assert(!(DMA & 2) || !PRO, "the input tile can only be staged by DMA when no prologue transforms it on the way into LDS");
   constexpr bool BF16 = G::BF16;                // 16-bit storage, bf16 or half (ST says which)
   constexpr int ST = PREC;
   constexpr int ESZ = BF16 ? 2 : 4;             // bytes per stored activation element
@@ -558,13 +577,16 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       return;
     }
     int aoff[MF];   // LDS float offset of this lane's pixel in the (dy, dx) window
+    int apix[MF];   // ... and its pixel index in the tile (the row of the XOR swizzle of a DMA-staged tile)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int r = fy[mf] * STRIDE + dy;
       const int c = STRIDE == 2 ? (dx & 1) * G::IWH + fx + (dx >> 1) : fx * STRIDE + dx;   // stride 2: de-interleaved columns
-      aoff[mf] = (r * G::IWP + c) * G::CK;
+      apix[mf] = r * G::IWP + c;
+      aoff[mf] = apix[mf] * G::AP;
     }
-    const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
+    const int rb0 = wn * NFE * 32 + li;      // this lane's filter row of column fragment 0
+    const float* sBrow = sB + buf * G::SB + rb0 * G::BP;
     static_assert(!BF16 || (BK % 16 == 0 && NF > 0), "bf16 matrix-core path: 16-channel steps, 32-column fragments");
     if constexpr (BF16) {
       {
@@ -597,9 +619,15 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       const int kb = kw * KBW + kj;
       float4 a[MF], b[NFE];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + lh * 4 + kb * 8);
+      for (int mf = 0; mf < MF; ++mf) {
+        if constexpr (DMA & 2) a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + G::swz(apix[mf], kb * 2 + lh) * 4);
+        else a[mf] = *reinterpret_cast<const float4*>(sA + aoff[mf] + lh * 4 + kb * 8);
+      }
 #pragma unroll
-      for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
+      for (int nf = 0; nf < NFE; ++nf) {
+        if constexpr (DMA & 1) b[nf] = *reinterpret_cast<const float4*>(sBrow + nf * 32 * G::BP + G::swz(rb0 + nf * 32, kb * 2 + lh) * 4);
+        else b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
+      }
       if constexpr (DUAL) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc[0][0], 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, accb, 0, 0, 0);
@@ -746,6 +774,92 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         compute_tap(dy, 2, buf * 3 + 2);
       }
     }
+  } else if constexpr (DMA != 0) {
+    // ---- operand tiles staged by LDS-DMA (see IgemmGeom).  ONE barrier per filter slice and no store phase: behind the
+    // barrier of slice t every wave issues the fill of slice t + 1 into the other filter buffer (and, at slice 0, the fill of
+    // the next chunk's input tile into the other tile buffer), then runs the MFMAs of slice t over them.  The DMA is inline
+    // assembly: the compiler's wait-count pass cannot tell LDS buffers apart and would wait for every fill before every
+    // ds_read.  Its own vmcnt waits (register-staged input tile of the prologue variants) stay correct: younger
+    // operations in flight only make an in-order vmcnt(k) wait stricter.
+    typedef __attribute__((address_space(3))) void lds_void;
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int S = G::SLOTS;
+    // filter slice: instruction qi = q * 4 + wave covers slots [qi * 64, + 64) of the [BN][S] slice; lane -> (row, physical slot)
+    const char* bsrc[G::NQB > 0 ? G::NQB : 1];
+#pragma unroll
+    for (int q = 0; q < G::NQB; ++q) {
+      const int L = (q * 4 + wave) * 64 + lane;
+      const int row = L / S, ls = G::swz(row, L % S);
+      bsrc[q] = wb + ((size_t)min(n0 + min(row, G::BN - 1), p.CoutPad - 1) * wrow + ls * 4) * 4;
+    }
+    auto fillB = [&](int buf, int kc, int tap) {
+#pragma unroll
+      for (int q = 0; q < G::NQB; ++q) {
+        if ((q * 4 + wv) * 64 < G::BN * S) {         // (wave-uniform: whole instructions beyond the slice are not issued)
+          const uint32_t dst = lds0 + (uint32_t)(G::NA * G::SA + buf * G::SB + (q * 4 + wv) * 256) * 4u;
+          const char* src = bsrc[q] + (size_t)(tap * p.Cin + kc) * 4;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+        }
+      }
+    };
+    // input tile: the same split; a slot outside the tile, outside the image (zero padding) or on a pad column reads zeros
+    const char* asrc[G::NQA > 0 ? G::NQA : 1];
+    unsigned amask = 0;                     // bit q: slot q of this lane is an in-image element (its address advances with the chunk)
+    if constexpr (DMA & 2) {
+#pragma unroll
+      for (int q = 0; q < G::NQA; ++q) {
+        const int L = (q * 4 + wave) * 64 + lane;
+        const int lp = L / S, ls = G::swz(lp, L % S);
+        const int ly = lp / G::IWP, c = lp % G::IWP;
+        int lx = c;
+        bool ok = lp < G::IH * G::IWP;
+        if constexpr (STRIDE == 2) {          // de-interleaved columns: [even columns | odd columns | pad]
+          if (c < G::IWH) lx = 2 * c;
+          else { lx = 2 * (c - G::IWH) + 1; ok = ok && lx < G::IW; }
+        }
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        asrc[q] = ok ? xn + ((size_t)(unsigned)((iy * p.Win + ix) * p.xC) + ls * 4) * 4 : reinterpret_cast<const char*>(p.zeros);
+        amask |= ok ? (1u << q) : 0u;
+      }
+    }
+    auto fillA = [&](int abuf, int kc) {
+#pragma unroll
+      for (int q = 0; q < G::NQA; ++q) {
+        const uint32_t dst = lds0 + (uint32_t)(abuf * G::SA + (q * 4 + wv) * 256) * 4u;
+        const char* src = asrc[q] + ((amask >> q) & 1u ? (size_t)kc * 4 : 0);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+      }
+    };
+    consumer_stats();                       // (uses smem as scratch: before the first fill)
+    if constexpr (DMA & 2) fillA(0, kc_begin); else prefetchA(kc_begin);
+    fillB(0, kc_begin, 0);
+    int abuf = 0, stage = 0;               // stage: running slice count (the slice count of a chunk may be odd: 9, 1)
+    for (int kc = kc_begin; kc < kc_end; kc += BK) {
+      if constexpr (!(DMA & 2)) {
+        __syncthreads();   // every wave is done reading sA of the previous chunk
+        writeA(false);
+      }
+#pragma unroll 1
+      for (int tap = 0; tap < G::TAPS; ++tap, ++stage) {
+        const int buf = stage & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slice `tap` (and, at slice 0, of the chunk's input tile) has landed
+        __syncthreads();                                      // ... and everybody's; everybody is done with slice tap - 1
+        {
+          int ntap = tap + 1, nkc = kc;
+          if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
+          if (nkc < kc_end) fillB(buf ^ 1, nkc, ntap);
+        }
+        if (tap == 0 && kc + BK < kc_end) {
+          if constexpr (DMA & 2) fillA(abuf ^ 1, kc + BK); else prefetchA(kc + BK);
+        }
+        if constexpr (DMA & 2) sA = smem + abuf * G::SA;
+        compute_tap(tap / KS, tap % KS, buf);
+      }
+      abuf ^= 1;
+    }
+    sA = smem;
   } else if constexpr ((RIB_EXP & 32) && KS == 1 && STRIDE == 1 && !UPS && PREC == PREC_F32 && TB == 1 && KW == 1 && !N16) {
     // EXPERIMENT (tools/probes/spade_harness.hip, -DRIB_EXP=32): 1x1 convolutions have no halo, so with WN == 1 every
     // input pixel is used by exactly one wave and staging it through LDS buys no reuse: read the A fragments straight

@@ -40,6 +40,8 @@
 #define RIB_VBX(sec, ...) RIB_I_VBX(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_V1D(sec, ...) RIB_I_V1D(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VS1D(sec, ...) RIB_I_VS1D(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VD(sec, ...) RIB_I_VD(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VSD(sec, ...) RIB_I_VSD(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
 #undef RIB_V
 #undef RIB_VK
@@ -53,6 +55,8 @@
 #undef RIB_VBX
 #undef RIB_V1D
 #undef RIB_VS1D
+#undef RIB_VD
+#undef RIB_VSD
 
 using namespace rib;
 
@@ -235,6 +239,8 @@ struct Variant {
   int TB = 1;                  // filter slices staged per barrier: 1 tap, or 3 = one row of a 3x3 filter
   // FRW == 0: not a k_igemm instantiation but a tile of k_gemm_dma (plain GEMM, operands staged by LDS-DMA): (32 WM) x (32 NF WN),
   // fp32 only; serves the batched Winograd-domain GEMMs and the condition-level gamma/beta GEMM
+  int DMAK = 0;                // k_igemm instantiations whose operand tiles are staged by LDS-DMA (filters always, the input tile in
+                               // the lean one); no fused-shortcut instantiation; reported as TB = 100 in the exported geometry
   typedef void (*GemmDmaFn)(const GemmDmaParams);
   GemmDmaFn gfn = nullptr;
   bool dma() const { return FRW == 0; }
@@ -244,6 +250,14 @@ struct Variant {
   int BN() const { return NF == 0 ? 16 * WN : 32 * NF * WN; }   // NF == 0: 16-column MFMA path
   int lds_bytes() const {
     if (dma()) return 2 * (BM() + BN()) * 32 * 4;
+    if (DMAK) {      // IgemmGeom with DMA: unpadded rows, whole DMA instructions, two input-tile buffers (lean) - the larger of lean / prologue
+      const int ih_ = (TH() - 1) * STRIDE + KS, iw_ = (TW() - 1) * STRIDE + KS;
+      const int iwp_ = (STRIDE == 2 && FRW == 8) ? ((iw_ + 3) / 8 * 8 + 4) : iw_;
+      const int sl = BK / 4;
+      const int sb = (BN() * sl + 255) / 256 * 256 * 4;
+      const int lean = 2 * ((ih_ * iwp_ * sl + 255) / 256 * 256 * 4) + 2 * sb, pro = ih_ * iwp_ * (BK + 4) + 2 * sb;
+      return (lean > pro ? lean : pro) * 4;
+    }
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
     const int ck = (BF16 != PREC_F32 ? BK / 2 : BK) + 4;   // IgemmGeom::CK
@@ -315,13 +329,22 @@ struct Variant {
   Variant{FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP,                                                                               \
           &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, UPS, SP, 2, (KS == 3 && S == 1 && !UPS && !SP), true, KW, TB>, 2, nullptr, nullptr, KW, TB},
 
+// RIB_VD / RIB_VSD: LDS-DMA-staged twins (variants.def)
+#define RIB_VD(sec, FRW, WM, WN, MF, NF, BK, S, KS) \
+  dmak_variant(Variant{FRW, WM, WN, MF, NF, BK, S, KS, false, false, nullptr, 0,                                          \
+                       &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, true, 1, 1, 1>,                   \
+                       &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, false, 1, 1, 3>}),
+#define RIB_VSD(sec, FRW, WM, WN, MF, NF, BK) \
+  dmak_variant(Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, false, false, 1, 1, 3>, 0}),
+
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
-  if (p.x2 != nullptr) return v->fn;
+  if (p.x2 != nullptr || (v->fn && !v->fn_pro)) return v->fn;
   if (p.pro_scale == nullptr && !p.pro_lrelu && v->fn_lean) return v->fn_lean;
   return v->fn_pro ? v->fn_pro : v->fn;
 }
 
+inline Variant dmak_variant(Variant v) { v.DMAK = 1; return v; }
 inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn) {
   Variant v{0, WM, WN, 1, NF, 32, 1, 1, false, false, nullptr};
   v.gfn = fn;
@@ -358,7 +381,7 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
-    if (v.dma()) continue;                  // (chosen by pick_gemm_dma)
+    if (v.dma() || v.DMAK) continue;        // (k_gemm_dma tiles: pick_gemm_dma; DMA-staged k_igemm twins: tuned choices only)
     if (v.STRIDE != stride || v.KS != ks || v.UPS != ups || v.SPADE != spade || Cin % v.BK != 0 || Cin2 % v.BK != 0) continue;
     if (v.NF == 0 && !allow_n16) continue;
     if (v.SPADE && v.NF == 1) continue;      // 16-channel SPADE layout: chosen explicitly (Builder::spade)
@@ -543,6 +566,7 @@ struct rib_handle {
   size_t d_blob_floats = 0;      // allocated size (the bf16 storage mode carries bf16 filter copies: a larger blob)
   std::vector<float> host_blob;   // host-only handles (device < 0) keep the folded blob here
   size_t blob_floats = 0;
+  size_t zero_off = 0;            // 64 floats of zeros in the blob: the source of zero-padding pixels for DMA-staged input tiles
   uint64_t layout_hash = 0;       // of the blob's offsets (assign_weight_layout); part of the blob header
   // Winograd-domain filter sets U = G g G^T, [positions][CoutPad][CinPad] fp32 each, made on the device from the folded
   // filters of the blob when a plan first asks for one (round 3: they were 391 of the blob's 514 MB, both sets of every layer,
@@ -694,6 +718,7 @@ void assign_weight_layout(rib_handle* h) {
   size_t off = BLOB_HEADER_FLOATS;
   h->spades.clear(); h->spade_index.clear();
   auto take = [&](size_t nfloats) { size_t o = off; off += (nfloats + 63) / 64 * 64; return o; };
+  h->zero_off = take(64);
   for (auto& c : h->convs) {
     if (!c.used) continue;
     c.cinp = h->padc(c.cin);
@@ -1013,7 +1038,7 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        const bool ok = !tv.dma() && tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+        const bool ok = !tv.dma() && !(tv.DMAK && (a.aux || ts != 1)) && tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
                         (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
@@ -2029,6 +2054,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.xm = R.get<const float>(op.xm); p.m_scale = R.get<const float>(op.m_scale); p.m_shift = R.get<const float>(op.m_shift);
         p.ys0 = R.get<float>(op.ys0); p.ys1 = R.get<float>(op.ys1);
         p.m_part = R.get<const double>(op.m_part);
+        p.zeros = R.blob + h->zero_off;
         if (op.small_co > 0 && op.head) {
           if (op.fuse_blend && R.user[U_FUSE]) {
             p.bl_img = reinterpret_cast<const float*>(R.user[U_IMG]); p.bl_dain = reinterpret_cast<const float*>(R.user[U_FAKE]);
@@ -2761,7 +2787,7 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
   else if (op.kind == OP_IGEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->TB,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->DMAK ? 100 : op.var->TB,
              op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
   else if (op.kind == OP_GEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|gemm (LDS-DMA staged operands) tile %dx%d BK 32, %d x [%d x %d x %d]%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
@@ -2781,7 +2807,7 @@ int rib_num_variants(void) { return kNumVariants; }
 int rib_variant_info(int idx, int geom[12]) {
   if (idx < 0 || idx >= kNumVariants || !geom) return RIB_ERR_INVALID;
   const Variant& v = kVariants[idx];
-  const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.TB};
+  const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.DMAK ? 100 : v.TB};
   for (int i = 0; i < 12; ++i) geom[i] = g[i];
   return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage, 2 half storage
 }

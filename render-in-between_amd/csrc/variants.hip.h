@@ -6,7 +6,7 @@
 // rib.hip's RIB_V / RIB_VK / ... table macros name the same instantiations; keep the two in step.
 #pragma once
 
-// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (0 fp32 / 1 bf16 / 2 half; false = 0), AUX, PRO, KW, TB
+// template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (0 fp32 / 1 bf16 / 2 half; false = 0), AUX, PRO, KW, TB, DMA
 #define RIB_F_EXTERN(...) extern template __global__ void rib::k_igemm<__VA_ARGS__>(const rib::IgemmParams);
 #define RIB_F_TOUCH(...) &rib::k_igemm<__VA_ARGS__>,
 
@@ -51,3 +51,8 @@
   F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, true, KW, 2)          \
   F(FRW, WM, WN, MF, NF, BK, 1, 1, false, false, 0, false, false, KW, 2)
 #define RIB_I_VS1D(F, FRW, WM, WN, MF, NF, BK, KW) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, true, true, KW, 2)
+// operand tiles staged by LDS-DMA: prologue instantiation (filters by DMA) + lean instantiation (filters and input tile); fused SPADE
+#define RIB_I_VD(F, FRW, WM, WN, MF, NF, BK, S, KS)                      \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, true, 1, 1, 1) \
+  F(FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, false, 1, 1, 3)
+#define RIB_I_VSD(F, FRW, WM, WN, MF, NF, BK) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, false, false, 1, 1, 3)

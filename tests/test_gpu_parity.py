@@ -870,6 +870,46 @@ def test_first_layers_read_the_callers_tensors_in_place(monkeypatch):
     monkeypatch.delenv("RIB_NO_LOWC", raising=False)
 
 
+def test_dma_staged_kernel_variants_agree_with_the_register_staged_ones():
+    """Round 3: k_igemm instantiations whose operand tiles are staged by LDS-DMA (global_load_lds_dwordx4; filters always,
+    the input tile where no prologue transforms it: unpadded XOR-swizzled LDS rows, zero padding read from a page of zeros,
+    stride-2 de-interleaving done by the source addresses) exist beside the register-staged ones and are picked by
+    measured choices only.  Here every convolution / fused-SPADE launch that admits one is pinned to its first fitting DMA
+    variant: same frame (summation order differs with the tile geometry only), odd sizes and batch included."""
+    import ctypes as C
+    from render_in_between_amd import _native
+    spec, sd, G0 = build("full", 0)
+    lib = _native.lib()
+    g12 = (C.c_int * 12)()
+    dma_idx = [i for i in range(lib.rib_num_variants()) if lib.rib_variant_info(i, g12) == 0 and g12[11] == 100]
+    assert len(dma_idx) >= 20
+    for (B, H, W) in ((1, 128, 128), (2, 48, 80), (1, 256, 256)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, 31)
+        i0, m0 = [t.clone() for t in G0(label, None, fake, prev)]
+        G1 = rib.Generator(rib.hsm_gen_config(), use_tuning=False).eval()
+        G1.load_state_dict(sd)
+        pinned = {}
+        for info in G1.launch_info(B, H, W):
+            if info["class"] not in (0, 1) or "tile " not in info["tile"] or "gemm" in info["tile"] or "wino" in info["tile"]:
+                continue
+            for vi in dma_idx:
+                lib.rib_set_choice(G1._h, B, H, W, info["name"].encode(), vi, 1)
+                if lib.rib_workspace_bytes(G1._h, B, H, W) > 0:
+                    pinned[info["name"]] = vi
+                    break
+                lib.rib_set_choice(G1._h, B, H, W, info["name"].encode(), -1, 1)
+        assert len(pinned) >= 15, (B, H, W, len(pinned))      # (the fused-shortcut, upsample, first-layer and head launches have no DMA twin)
+        G1._ws.clear()
+        i1, m1 = G1(label, None, fake, prev)
+        staged = [x["tile"] for x in G1.launch_info(B, H, W) if x["name"] in pinned]
+        assert all("tb100" in t for t in staged), staged[:3]
+        d = (float((i1 - i0).abs().max()), float((m1 - m0).abs().max()))
+        assert d[0] <= 5e-5 and d[1] <= 5e-5, (B, H, W, d, len(pinned))
+        oi, om = oracle(spec, sd)(label, None, fake, prev)
+        assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL
+        del G1
+
+
 def test_sixteen_channel_spade_layout_agrees_with_the_pair_layout(monkeypatch):
     """down_0.1 / up_0.1 modulate 16 channels: by default one [gamma(16) | beta(16)] MFMA fragment per wave (k_igemm<SPADE,
     NF = 1>, the halves exchange rows with shuffles); with RIB_NO_SPADE16 the pair layout every other SPADE uses.  Same

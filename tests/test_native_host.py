@@ -226,7 +226,7 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
         if lib.rib_variant_info(i, g12) == 0:            # fp32 variants (this table is measured in fp32)
             geoms.add(tuple(g12))
     table = tuning.load()
-    assert "1,512,512" in table and len(table["1,512,512"]) >= 50      # (round 3: 59 tunable launches at 512x512, 56 with a measured winner)
+    assert "1,512,512" in table and len(table["1,512,512"]) >= 40      # (round 3: 59 tunable launches at 512x512; those whose default is the measured winner have no entry)
     stale = []
     for shape, entry in table.items():
         for op, ch in entry.items():
