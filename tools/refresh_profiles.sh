@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r02
+#   bash tools/refresh_profiles.sh r03
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench
 cp $OUT/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 echo "[refresh] per-op table"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_prof_ops.log 2>&1
-python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops > $OUT/${TAG}_prof_ops_512.txt
+python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops --json $OUT/${TAG}_prof_ops_512.json > $OUT/${TAG}_prof_ops_512.txt
 echo "[refresh] PMC passes (separate runs, kernel trace only)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_w.log 2>&1
@@ -31,7 +31,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_I
 done
 echo "[refresh] other shapes and modes"
 rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
-for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
+for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype f16" "--dtype f16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
@@ -42,6 +42,14 @@ echo "[refresh] multi-rank rehearsal on one GPU (2 ranks share device 0, gloo in
 cd $ROOT
 RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --mode clips --steps 3 --warmup 1 > $OUT/${TAG}_clips_2ranks_1gpu.json 2> $OUT/${TAG}_clips_2ranks_1gpu.err
 cd /tmp
+echo "[refresh] k_warp: timing + FETCH / WRITE counters"
+python3 $ROOT/tools/warp_bench.py --time --out $OUT/${TAG}_warp.json > $OUT/${TAG}_warp.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/warp_f -- python3 $ROOT/tools/warp_bench.py --run > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/warp_w -- python3 $ROOT/tools/warp_bench.py --run > /dev/null 2>&1
+python3 $ROOT/tools/warp_bench.py --report $OUT/warp_f $OUT/warp_w --out $OUT/${TAG}_warp_pmc.json > $OUT/${TAG}_warp_pmc.log 2>&1
+rm -rf $OUT/warp_f $OUT/warp_w
+echo "[refresh] LDS-DMA probe"
+[ -x $ROOT/tools/probes/bin/ldsdma_probe ] && timeout -k 10 120 $ROOT/tools/probes/bin/ldsdma_probe > $OUT/${TAG}_ldsdma_probe.txt 2>&1
 echo "[refresh] motion transformer"
 python3 $ROOT/tools/motion_bench.py --out $OUT/${TAG}_motion_bench.json > $OUT/${TAG}_motion_bench.log 2>&1
 rm -rf $OUT/prof_bench $OUT/prof_ops $OUT/pmc_f $OUT/pmc_w $OUT/prof_bf16
