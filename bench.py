@@ -237,14 +237,26 @@ def main():
     # k_conv_head) PLUS the launches that are part of computing those same convolutions: Winograd input / output
     # transforms and split-K slab sums (class "conv_aux").  Round 2 left the latter out of the denominator (VERDICT r02
     # weak #2): the class time below includes them.
-    mm_ms = prof["igemm"]["ms"] / nprof
-    aux_ms = prof["conv_aux"]["ms"] / nprof
+    # One event in front of every launch makes the profiled step longer than the timed one (the event record sits between
+    # two launches): that difference, spread evenly over the launches, is the event overhead per launch, and it is taken
+    # off every class in proportion to its launch count.  The corrected classes add up to the TIMED step, which is what the
+    # rocprofv3 kernel trace of the same step shows (profiles/rNN_prof_ops_512.txt); raw event figures are kept beside them.
+    n_launch = sum(v["launches"] for v in prof.values()) / nprof
+    profiled_step_ms = sum(v["ms"] for v in prof.values()) / nprof       # the raw classes add up to the (profiled) step
+    step_ms_one = ms_per_step / (frames_per_step / B) if args.mode != "frame" else ms_per_step     # per forward
+    ev_over_ms = max(0.0, profiled_step_ms - step_ms_one) / max(1.0, n_launch)
+
+    def corrected(name):
+        return max(0.0, prof[name]["ms"] / nprof - prof[name]["launches"] / nprof * ev_over_ms)
+
+    mm_ms = corrected("igemm")
+    aux_ms = corrected("conv_aux")
     conv_ms = mm_ms + aux_ms
+    conv_ms_raw = (prof["igemm"]["ms"] + prof["conv_aux"]["ms"]) / nprof
     conv_launches = (prof["igemm"]["launches"] + prof["conv_aux"]["launches"]) / nprof
     conv_tflops = flops["igemm"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    spade_ms = prof["spade"]["ms"] / nprof
-    classes = {k: {"launches_per_step": v["launches"] / nprof, "ms_per_step": v["ms"] / nprof} for k, v in prof.items()}
-    profiled_step_ms = sum(v["ms"] for v in prof.values()) / nprof       # the classes add up to the (profiled) step
+    spade_ms = corrected("spade")
+    classes = {k: {"launches_per_step": v["launches"] / nprof, "ms_per_step": corrected(k), "ms_per_step_raw_events": v["ms"] / nprof} for k, v in prof.items()}
     # executed matrix work: the three mask-network upsample convolutions run as 2x2 phase convolutions, 4/9 of their
     # nine-tap count, the Winograd-domain GEMMs execute 4/9 (F(2x2)) or 1/4 (F(4x4)) of theirs; everything
     # else executes what it is priced at (channel padding not counted)
@@ -299,6 +311,8 @@ def main():
         "frac": conv_tflops / peak,
         "avg_launch_us": conv_ms * 1e3 / max(1.0, conv_launches),
         "class_ms_per_step": conv_ms, "matrix_core_launches_ms_per_step": mm_ms, "transform_and_splitk_sum_launches_ms_per_step": aux_ms,
+        "class_ms_per_step_raw_events": conv_ms_raw, "frac_raw_events": (flops["igemm"] / (conv_ms_raw * 1e-3) / 1e12 / peak) if conv_ms_raw > 0 else 0.0,
+        "event_overhead_us_per_launch": ev_over_ms * 1e3,
         "algorithmic_gflop_per_step": flops["igemm"] / 1e9,
         "executed_gflop_per_step": executed / 1e9,
         "executed_tflops": executed / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
@@ -308,7 +322,7 @@ def main():
         "traffic_bytes_per_step_all_classes": traffic_step,
         "traffic_source": traffic_src,
         "classes": classes,
-        "profiled_step_ms": profiled_step_ms,
+        "profiled_step_ms": profiled_step_ms, "timed_step_ms": step_ms_one,
         "spade_tflops": flops["spade"] / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0,
         "whole_step_frac_of_mfma_roof": (sum(flops.values()) * (frames_per_step / B) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (ms_per_step * 1e-3),
         "whole_step_algorithmic_hbm_gbs": hbm_gbs, "whole_step_frac_of_hbm_roof": hbm_gbs / PEAK_HBM_GBS,

@@ -64,6 +64,7 @@
 #define RIB_VS1D(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VS1D(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VD(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VD(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VSD(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VSD(RIB_F_TOUCH, __VA_ARGS__))
+#define RIB_VD9(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VD9(RIB_F_TOUCH, __VA_ARGS__))
 
 typedef void (*IgemmFn)(const rib::IgemmParams);
 extern "C" __attribute__((used, visibility("hidden"))) IgemmFn const RIB_CAT(rib_igemm_section_, RIB_SECTION)[] = {

@@ -300,7 +300,8 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // and fits 99-104 registers without spilling.
 __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
-  static_assert(DMA == 0 || (PREC == PREC_F32 && TB == 1 && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)), "DMA staging: fp32, one slice per barrier, 32-column path, no fused shortcut");
+  static_assert(DMA == 0 || (PREC == PREC_F32 && (TB == 1 || (TB == 9 && DMA == 3 && KS == 3)) && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)),
+                "DMA staging: fp32, 32-column path, no fused shortcut; one slice per barrier, or all nine of a chunk with a DMA-staged input tile");
   static_assert(!(DMA & 2) || !PRO, "the input tile can only be staged by DMA when no prologue transforms it on the way into LDS");
   constexpr bool BF16 = G::BF16;                // 16-bit storage, bf16 or half (ST says which)
   constexpr int ST = PREC;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB(buf ^ 1); }
     }
     sA = smem;
-  } else if constexpr (TB == 9) {
+  } else if constexpr (TB == 9 && DMA == 0) {
     // all nine filter slices of a chunk staged at once; input tile AND filters double-buffered across chunks, so a
     // chunk costs ONE barrier: chunk k+1 is written to the other buffers right after the MFMAs of chunk k (its
     // global loads were in flight during them); whoever is past the barrier of chunk k has finished chunk k-1
@@ -833,6 +834,29 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       }
     };
     consumer_stats();                       // (uses smem as scratch: before the first fill)
+    if constexpr (TB == 9) {
+      // k_gemm_dma's cadence for a 3x3 convolution: a stage = the input tile + all nine filter slices of a channel chunk, two
+      // stages, ONE barrier per chunk; behind it the fills of the next chunk are issued and the 9 x (BK / 8) MFMA steps of this
+      // one run over them.  The register-staged TB = 9 variants paid 9 x NB4 staging registers for this cadence; these pay none.
+      fillA(0, kc_begin);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) fillB(t, kc_begin, t);
+      int st = 0;
+      for (int kc = kc_begin; kc < kc_end; kc += BK) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // the chunk has landed; everybody is done with the previous one (its stage is free)
+        if (kc + BK < kc_end) {
+          fillA(st ^ 1, kc + BK);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) fillB((st ^ 1) * 9 + t, kc + BK, t);
+        }
+        sA = smem + st * G::SA;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) compute_tap(t / 3, t % 3, st * 9 + t);
+        st ^= 1;
+      }
+      sA = smem;
+    } else {
     if constexpr (DMA & 2) fillA(0, kc_begin); else prefetchA(kc_begin);
     fillB(0, kc_begin, 0);
     int abuf = 0, stage = 0;               // stage: running slice count (the slice count of a chunk may be odd: 9, 1)
@@ -860,6 +884,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       abuf ^= 1;
     }
     sA = smem;
+    }
   } else if constexpr ((RIB_EXP & 32) && KS == 1 && STRIDE == 1 && !UPS && PREC == PREC_F32 && TB == 1 && KW == 1 && !N16) {
     // EXPERIMENT (tools/probes/spade_harness.hip, -DRIB_EXP=32): 1x1 convolutions have no halo, so with WN == 1 every
     // input pixel is used by exactly one wave and staging it through LDS buys no reuse: read the A fragments straight

@@ -42,6 +42,7 @@
 #define RIB_VS1D(sec, ...) RIB_I_VS1D(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VD(sec, ...) RIB_I_VD(RIB_F_EXTERN, __VA_ARGS__)
 #define RIB_VSD(sec, ...) RIB_I_VSD(RIB_F_EXTERN, __VA_ARGS__)
+#define RIB_VD9(sec, ...) RIB_I_VD9(RIB_F_EXTERN, __VA_ARGS__)
 #include "variants.def"
 #undef RIB_V
 #undef RIB_VK
@@ -57,6 +58,7 @@
 #undef RIB_VS1D
 #undef RIB_VD
 #undef RIB_VSD
+#undef RIB_VD9
 
 using namespace rib;
 
@@ -255,8 +257,8 @@ struct Variant {
       const int iwp_ = (STRIDE == 2 && FRW == 8) ? ((iw_ + 3) / 8 * 8 + 4) : iw_;
       const int sl = BK / 4;
       const int sb = (BN() * sl + 255) / 256 * 256 * 4;
-      const int lean = 2 * ((ih_ * iwp_ * sl + 255) / 256 * 256 * 4) + 2 * sb, pro = ih_ * iwp_ * (BK + 4) + 2 * sb;
-      return (lean > pro ? lean : pro) * 4;
+      const int lean = 2 * ((ih_ * iwp_ * sl + 255) / 256 * 256 * 4) + 2 * TB * sb, pro = ih_ * iwp_ * (BK + 4) + 2 * sb;
+      return (TB == 9 || lean > pro ? lean : pro) * 4;
     }
     const int ih = UPS ? TH() + 2 : (TH() - 1) * STRIDE + KS, iw = UPS ? TW() + 2 : (TW() - 1) * STRIDE + KS;
     const int iwp = (STRIDE == 2 && FRW == 8) ? ((iw + 3) / 8 * 8 + 4) : iw;   // IgemmGeom::IWP
@@ -336,6 +338,10 @@ struct Variant {
                        &k_igemm<FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, false, 1, 1, 3>}),
 #define RIB_VSD(sec, FRW, WM, WN, MF, NF, BK) \
   dmak_variant(Variant{FRW, WM, WN, MF, NF, BK, 1, 1, false, true, &k_igemm<FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, false, false, 1, 1, 3>, 0}),
+
+#define RIB_VD9(sec, FRW, WM, WN, MF, NF, BK, S) \
+  dmak_variant(Variant{FRW, WM, WN, MF, NF, BK, S, 3, false, false, nullptr, 0, nullptr,                                   \
+                       &k_igemm<FRW, WM, WN, MF, NF, BK, S, 3, false, false, 0, false, false, 1, 9, 3>, 1, 9}),
 
 // the leanest instantiation that covers a launch
 inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
@@ -1038,7 +1044,7 @@ struct Builder {
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
-        const bool ok = !tv.dma() && !(tv.DMAK && (a.aux || ts != 1)) && tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
+        const bool ok = !tv.dma() && !(tv.DMAK && (a.aux || ts != 1)) && !(tv.DMAK && !tv.fn_pro && !tv.fn && (a.pro || a.pro_lrelu)) && tv.BF16 == h->prec() && tv.STRIDE == c.stride && tv.KS == c.ks && tv.UPS == a.ups && !tv.SPADE && c.cinp % tv.BK == 0 &&
                         (!a.aux || a.aux->cinp % tv.BK == 0) && (tv.NF != 0 || (can_n16 && ts == 1)) &&
                         ts >= 1 && ts <= c.cinp / tv.BK && (ts == 1 || can_split);
         if (!ok) { error = fmt("%s: tuned choice (variant %d, ksplit %d) does not fit this layer", opname.c_str(), it->second.first, ts); return false; }
@@ -2787,7 +2793,7 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
   else if (op.kind == OP_IGEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
-             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->DMAK ? 100 : op.var->TB,
+             op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->DMAK ? 100 + (op.var->TB == 9 ? 9 : 0) : op.var->TB,
              op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
   else if (op.kind == OP_GEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|gemm (LDS-DMA staged operands) tile %dx%d BK 32, %d x [%d x %d x %d]%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
@@ -2807,7 +2813,7 @@ int rib_num_variants(void) { return kNumVariants; }
 int rib_variant_info(int idx, int geom[12]) {
   if (idx < 0 || idx >= kNumVariants || !geom) return RIB_ERR_INVALID;
   const Variant& v = kVariants[idx];
-  const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.DMAK ? 100 : v.TB};
+  const int g[12] = {v.FRW, v.WM, v.WN, v.MF, v.NF, v.BK, v.STRIDE, v.KS, v.UPS ? 1 : 0, v.SPADE ? 1 : 0, v.KW, v.DMAK ? 100 + (v.TB == 9 ? 9 : 0) : v.TB};
   for (int i = 0; i < 12; ++i) geom[i] = g[i];
   return v.BF16;   // precision of the instantiation: 0 fp32, 1 bf16 storage, 2 half storage
 }

@@ -56,3 +56,4 @@
   F(FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, true, 1, 1, 1) \
   F(FRW, WM, WN, MF, NF, BK, S, KS, false, false, 0, false, false, 1, 1, 3)
 #define RIB_I_VSD(F, FRW, WM, WN, MF, NF, BK) F(FRW, WM, WN, MF, NF, BK, 1, 1, false, true, 0, false, false, 1, 1, 3)
+#define RIB_I_VD9(F, FRW, WM, WN, MF, NF, BK, S) F(FRW, WM, WN, MF, NF, BK, S, 3, false, false, 0, false, false, 1, 9, 3)
