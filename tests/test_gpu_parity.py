@@ -914,6 +914,38 @@ def test_dma_staged_kernel_variants_agree_with_the_register_staged_ones():
         del G1
 
 
+def test_every_gemm_dma_tile_computes_the_same_frame():
+    """k_gemm_dma (the Winograd position GEMMs and the condition-level gamma/beta GEMMs) has five tiles, 64x64 ... 128x128.
+    Every GEMM launch of the plan is pinned to each tile in turn: same frame as the default plan, odd sizes (ragged M)
+    included.  (Round 3 also measured a three-stage LDS ring for the small tiles and an XCD-aware workgroup order: neither
+    moved the GEMMs - DESIGN "Round 3" - and neither is in the library.)"""
+    import ctypes as C
+    from render_in_between_amd import _native
+    spec, sd, G0 = build("full", 0)
+    lib = _native.lib()
+    g12 = (C.c_int * 12)()
+    tiles = [i for i in range(lib.rib_num_variants()) if lib.rib_variant_info(i, g12) == 0 and g12[0] == 0]      # FRW = 0: a k_gemm_dma tile
+    assert len(tiles) == 5, tiles
+    for (B, H, W) in ((1, 256, 256), (2, 80, 112)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, 37)
+        i0, m0 = [t.clone() for t in G0(label, None, fake, prev)]
+        names = [x["name"] for x in G0.launch_info(B, H, W) if "gemm (LDS-DMA" in x["tile"]]
+        assert len(names) >= 10, names
+        seen = set()
+        for vi in tiles:
+            G1 = rib.Generator(rib.hsm_gen_config(), use_tuning=False).eval()
+            G1.load_state_dict(sd)
+            for n in names:
+                lib.rib_set_choice(G1._h, B, H, W, n.encode(), vi, 1)
+            assert lib.rib_workspace_bytes(G1._h, B, H, W) > 0, vi
+            seen.update(x["tile"].split(",")[0] for x in G1.launch_info(B, H, W) if x["name"] in names)
+            i1, m1 = G1(label, None, fake, prev)
+            d = (float((i1 - i0).abs().max()), float((m1 - m0).abs().max()))
+            assert d[0] <= 5e-5 and d[1] <= 5e-5, (B, H, W, vi, d)
+            del G1
+        assert len(seen) == 5, seen
+
+
 def test_sixteen_channel_spade_layout_agrees_with_the_pair_layout(monkeypatch):
     """down_0.1 / up_0.1 modulate 16 channels: by default one [gamma(16) | beta(16)] MFMA fragment per wave (k_igemm<SPADE,
     NF = 1>, the halves exchange rows with shuffles); with RIB_NO_SPADE16 the pair layout every other SPADE uses.  Same
