@@ -2588,6 +2588,12 @@ struct LowcParams {
   int tilesX, tilesY;
 };
 
+#if RIB_EXP & 1024
+__device__ long long* g_lowc_stamps;      // tools/probes/lowc_harness.hip: [workgroup][8] s_memtime stamps of the phases
+#define RIB_STAMP(i) do { if (threadIdx.x == 0) g_lowc_stamps[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define RIB_STAMP(i) do { } while (0)
+#endif
 template <int CE, int NCOL, int ST, int TW = 32>
 __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   constexpr bool N16 = NCOL == 16;
@@ -2608,6 +2614,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   const int ty0 = (tile / p.tilesX) * TH, tx0 = (tile % p.tilesX) * TW;
   const int ctot = p.c0 + p.c1 + p.c2;
   const size_t HW = (size_t)p.H * p.W;
+  RIB_STAMP(0);
   // ---- stage the halo tile: all of a thread's loads are issued before the first LDS store (one memory round trip) ----
   {
     constexpr int TOT = CE * IH * IW, NIT = (TOT + 255) / 256;
@@ -2619,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       const int y = rem / IW, x = rem - y * IW;
       const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
       v[it] = 0.f;
-      if (i < TOT && c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+      if (!(RIB_EXP & 256) && i < TOT && c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
         const float* src; int cc, cn;
         if (c < p.c0) { src = p.s0; cc = c; cn = p.c0; }
         else if (c < p.c0 + p.c1) { src = p.s1; cc = c - p.c0; cn = p.c1; }
@@ -2635,6 +2642,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       if (i < TOT) sA[(y * IW + x) * CP + c] = v[it];
     }
   }
+  RIB_STAMP(1);
   // ---- this lane's filter fragments (registers; after the staging so that its 30 values in flight are dead: 116 instead
   // of 198 VGPRs on the 22-channel layers) ----
   // More than 64 of them (the 22-channel layers: 99) are loaded in two halves: 99 + 32 accumulators is 3 waves per SIMD,
@@ -2652,6 +2660,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   };
   load_b(0);
   __syncthreads();
+  RIB_STAMP(2);
   double s1 = 0.0, s2 = 0.0;                      // this lane's column: sum and sum of squares over its valid pixels
   if constexpr (!N16) {
     const int li = lane & 31, lh = lane >> 5;
@@ -2677,11 +2686,18 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
           for (int mf = 0; mf < MF; ++mf) {
             const float a = pa[off + mf * IW * CP];
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[sl][nf], acc[mf][nf], 0, 0, 0);
+            for (int nf = 0; nf < NF; ++nf) {
+              if (RIB_EXP & 64) acc[mf][nf][0] += a * bw[sl][nf];      // (tools/probes/lowc_harness.hip: the kernel without its MFMAs)
+              else acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[sl][nf], acc[mf][nf], 0, 0, 0);
+            }
           }
         }
       }
     }
+#if RIB_EXP & 1024
+    if (acc[0][0][0] == 123.456f) g_lowc_stamps[1 << 20] = 1;      // (the stamp waits for the accumulators)
+#endif
+    RIB_STAMP(3);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int col = nf * 32 + li;
@@ -2698,9 +2714,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
           float v = apply_act(acc[mf][nf][r] + bv, p.act);
           if (ST != ST_F32) v = round16<ST>(v);
           const bool ok = cok && oy < p.H && ox < p.W;
-          if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+          if (ok && (!(RIB_EXP & 128) || v == 123.456f)) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
           v = ok ? v : 0.f;
-          c1 += (double)v; c2 += (double)v * (double)v;
+          if (!(RIB_EXP & 512)) { c1 += (double)v; c2 += (double)v * (double)v; }
         }
       }
       if (p.stat_part) {
@@ -2722,8 +2738,11 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       const int tap = (4 * s) / CE, c = (4 * s) % CE;
       const int off = ((tap / 3) * IW + (tap % 3)) * CP + c;
 #pragma unroll
-      for (int f = 0; f < NFR; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[off + (TW == 32 ? ((f >> 1) * IW + (f & 1) * 16) : f * IW) * CP], bw[s][0], acc[f], 0, 0, 0);
+      for (int f = 0; f < NFR; ++f) {
+        const float a = pa[off + (TW == 32 ? ((f >> 1) * IW + (f & 1) * 16) : f * IW) * CP];
+        if (RIB_EXP & 64) acc[f][0] += a * bw[s][0];
+        else acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][0], acc[f], 0, 0, 0);
+      }
     }
     const int col = l15;
     const float bv = p.bias[col];
@@ -2737,9 +2756,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
         float v = apply_act(acc[f][r] + bv, p.act);
         if (ST != ST_F32) v = round16<ST>(v);
         const bool ok = cok && oy < p.H && ox < p.W;
-        if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+        if (ok && (!(RIB_EXP & 128) || v == 123.456f)) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
         v = ok ? v : 0.f;
-        s1 += (double)v; s2 += (double)v * (double)v;
+        if (!(RIB_EXP & 512)) { s1 += (double)v; s2 += (double)v * (double)v; }
       }
     }
     if (p.stat_part) {
@@ -2748,6 +2767,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       if (lq == 0) { red[wave][col][0] = s1; red[wave][col][1] = s2; }
     }
   }
+  RIB_STAMP(4);
   if (p.stat_part) {
     __syncthreads();
     for (int c = tid; c < p.CoutPad; c += 256) {
@@ -2763,6 +2783,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       }
     }
   }
+  RIB_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def plan_names(B, H, W):
+def plan_names(B, H, W, dtype="f32"):
     import render_in_between_amd as rib
     from render_in_between_amd import _native
     lib = _native.lib()
@@ -28,7 +28,8 @@ def plan_names(B, H, W):
     h = C.c_void_p()
     assert lib.rib_create(C.byref(c), -1, C.byref(h)) == 0
     from render_in_between_amd import tuning
-    tuning.apply(lib, h, tuning.load(), B, H, W)      # the same pinned choices Generator applies
+    assert lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1, "f16": 3}[dtype]) == 0
+    tuning.apply(lib, h, tuning.load(dtype=dtype), B, H, W, dtype=dtype)      # the same pinned choices Generator applies
     buf = C.create_string_buffer(512)
     out = []
     for i in range(lib.rib_num_launches(h, B, H, W)):
@@ -44,7 +45,7 @@ def run(args):
     from render_in_between_amd import synth
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
-    G = rib.Generator(cfg).eval()
+    G = rib.Generator(cfg, compute_dtype=args.dtype).eval()
     G.load_state_dict(synth.make_state_dict(spec, 0))
     label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, args.batch, args.size, args.size, 0)]
     torch.cuda.synchronize()
@@ -61,7 +62,7 @@ def report(args):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    ops = plan_names(args.batch, args.size, args.size)
+    ops = plan_names(args.batch, args.size, args.size, args.dtype)
     rows = [r for r in rows if r[2].startswith(("void rib::", "rib::"))]
     n = len(ops)
     total_steps = len(rows) // n
@@ -99,6 +100,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32")
     a = ap.parse_args()
     if a.run:
         run(a)
