@@ -2,6 +2,8 @@
 // A copy of the kernel's loop with parts switched off, timed in one process:
 //   0 full | 1 no MFMA (LDS reads folded with adds) | 2 no LDS reads (MFMA on registers) | 3 no fills | 4 MFMA only
 //   5 full, no C store | 6 no barrier (wrong results; fills + reads + MFMA free-running)
+//   7 full, the next chunk's fills issued BETWEEN the k steps of this chunk's MFMAs instead of in front of them
+//   8 full, all of the next chunk's fills issued behind the FIRST k step's MFMAs (an MFMA-first head)
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/probes/gemm_limits.hip -o tools/probes/bin/gemm_limits
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void k(const P p) {
     const int st = c & 1;
     if (ABL != 4 && ABL != 6) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ABL == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (c + 1 < nch) fill(st ^ 1, (c + 1) * BK);
+    if (ABL != 7 && ABL != 8 && c + 1 < nch) fill(st ^ 1, (c + 1) * BK);
     const float* sA = smem + st * STAGE;
     const float* sB = sA + BM * BK;
 #pragma unroll
@@ -74,6 +76,15 @@ __global__ __launch_bounds__(256) void k(const P p) {
         }
       }
       if (ABL == 2 || ABL == 4) { ra.x += 1.f; rbv.y += 1.f; }
+      if (ABL == 8 && kb == 0 && c + 1 < nch) fill(st ^ 1, (c + 1) * BK);
+      if (ABL == 7 && c + 1 < nch) {
+        constexpr int PER = (NFILL + 3) / 4;      // fill instructions per k step (4 k steps per chunk)
+#pragma unroll
+        for (int j = kb * PER; j < (kb + 1) * PER && j < NFILL; ++j) {
+          const uint32_t dst = lds0 + (uint32_t)((st ^ 1) * STAGE + (wave * 8 + 32 * j) * BK) * 4u;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src[j] + (c + 1) * BK) : "memory");
+        }
+      }
     }
   }
   float* C = p.C + (size_t)z * p.sC;
@@ -113,7 +124,7 @@ template <int WM, int WN, int NF> void run(const char* name, int Z, int M, int N
   P p{A, B, C, M, N, K, (size_t)M * K, (size_t)N * K, (size_t)M * N};
   dim3 g((M + BM - 1) / BM, (N + BN - 1) / BN, Z);
   const double fl = 2.0 * Z * M * N * K;
-  float t[7];
+  float t[9];
   t[0] = time_us([&] { k<WM, WN, NF, 0><<<g, 256>>>(p); });
   t[1] = time_us([&] { k<WM, WN, NF, 1><<<g, 256>>>(p); });
   t[2] = time_us([&] { k<WM, WN, NF, 2><<<g, 256>>>(p); });
@@ -121,8 +132,10 @@ template <int WM, int WN, int NF> void run(const char* name, int Z, int M, int N
   t[4] = time_us([&] { k<WM, WN, NF, 4><<<g, 256>>>(p); });
   t[5] = time_us([&] { k<WM, WN, NF, 5><<<g, 256>>>(p); });
   t[6] = time_us([&] { k<WM, WN, NF, 6><<<g, 256>>>(p); });
-  printf("%-34s tile %3dx%-3d grid %4d  full %6.1f (%3.0f TF) | noMFMA %6.1f | noLDSread %6.1f | noFill %6.1f | MFMAonly %6.1f | noStore %6.1f | noBarrier %6.1f   ideal %5.1f\n",
-         name, BM, BN, g.x * g.y * g.z, t[0], fl / t[0] / 1e6, t[1], t[2], t[3], t[4], t[5], t[6], fl / 157.3e6);
+  t[7] = time_us([&] { k<WM, WN, NF, 7><<<g, 256>>>(p); });
+  t[8] = time_us([&] { k<WM, WN, NF, 8><<<g, 256>>>(p); });
+  printf("%-34s tile %3dx%-3d grid %4d  full %6.1f (%3.0f TF) | noMFMA %6.1f | noLDSread %6.1f | noFill %6.1f | MFMAonly %6.1f | noStore %6.1f | noBarrier %6.1f | fills interleaved %6.1f (%3.0f TF) | fills behind k step 0 %6.1f (%3.0f TF)   ideal %5.1f\n",
+         name, BM, BN, g.x * g.y * g.z, t[0], fl / t[0] / 1e6, t[1], t[2], t[3], t[4], t[5], t[6], t[7], fl / t[7] / 1e6, t[8], fl / t[8] / 1e6, fl / 157.3e6);
   hipFree(A); hipFree(B); hipFree(C);
 }
 
@@ -136,6 +149,11 @@ int main() {
   run<2, 2, 1>("16 x [256 x 256 x 256]", 16, 256, 256, 256);
   run<2, 2, 4>("1 x [4096 x 2048 x 512]", 1, 4096, 2048, 512);
   run<2, 2, 4>("1 x [1024 x 8192 x 512]", 1, 1024, 8192, 512);
+  run<2, 2, 2>("1 x [4096 x 2048 x 512]", 1, 4096, 2048, 512);
+  run<2, 2, 2>("36 x [256 x 256 x 512]", 36, 256, 256, 512);
+  run<2, 2, 1>("36 x [256 x 256 x 512]", 36, 256, 256, 512);
+  run<4, 1, 4>("1 x [4096 x 2048 x 512]", 1, 4096, 2048, 512);
+  run<4, 1, 4>("1 x [1024 x 8192 x 512]", 1, 1024, 8192, 512);
   run<2, 2, 1>("empty-ish 36 x [256 x 256 x 32]", 36, 256, 256, 32);
   return 0;
 }
