@@ -217,6 +217,10 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // fp32 storage, operands split into three bf16 terms, six bf16 MFMAs per step - never beat fp32 once the deep layers ran
 // in the Winograd domain and was retired in round 3.)
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };      // = ST_F32 / ST_BF16 / ST_F16
+// DMA bit 2 (value 4, "WS"): warp-specialised workgroup of 8 waves - waves 4-7 only stage operands (global -> registers -> LDS,
+// or the DMA fills), waves 0-3 only read fragments and issue MFMAs; see the WS loops in k_igemm.  EXPERIMENT: instantiated by
+// tools/probes/igemm_harness.hip only (bit-identical results, no gain: profiles/r03_igemm_ws_probe.txt, DESIGN "Round 3");
+// no variant of the library uses it.
 // DMA (round 3): bit 0 = the filter slices, bit 1 = the input tile are staged by LDS-DMA (global_load_lds_dwordx4: no staging
 // registers, no ds_write) instead of global -> registers -> LDS.  A DMA instruction lands 64 consecutive 16-byte slots, so the
 // rows of a DMA-staged tile are NOT padded; the 16-byte slot of a row is XOR-swizzled instead (swz below), which is
@@ -265,7 +269,7 @@ struct IgemmGeom {
   static constexpr int SRED = WM * BN * 4;     // floats: [WM][BN][2] fp64 statistics partials
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   // TB = 9 (3x3) and TB = 2 (1x1: "chunk pairs") also double-buffer the input tile: one barrier per chunk
-  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2) || (DMA & 2)) ? 2 : 1;
+  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2) || (DMA & 2) || (DMA & 4)) ? 2 : 1;      // (DMA & 4: loader waves write the next chunk's tile)
   static constexpr int TBB = (KS == 1 && TB == 2) ? 1 : TB;   // filter slices per buffer
   static constexpr int SMEM0 = NA * SA + 2 * TBB * SB > SRED ? NA * SA + 2 * TBB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
@@ -291,6 +295,16 @@ struct IgemmGeom {
 // row -1 / H is exactly where the upsampled row -1 / 2H falls).  A workgroup owns a TH x TW tile of
 // SOURCE pixels and keeps four accumulator sets, one per phase; filter slice t = phase*4 + a*2 + b
 // multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
+#if RIB_EXP & 2048
+// tools/probes/igemm_harness.hip: where a wave's time goes in the main loop.  [workgroup * waves + wave][4] cycles:
+// 0 chunk head (barrier + input-tile commit), 1 filter store / fill issue, 2 waiting at the slice barrier, 3 the MFMA section
+__device__ long long* g_igemm_stamps;
+#define RIB_TS(v) const long long v = clock64()
+#define RIB_TACC(i, a, b) tacc[i] += (b) - (a)
+#else
+#define RIB_TS(v) do { } while (0)
+#define RIB_TACC(i, a, b) do { } while (0)
+#endif
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, int PREC = 0,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1, int DMA = 0>
 // Second launch bound = minimum waves per SIMD the register allocator must leave room for.  The fp32 variants with
@@ -298,10 +312,18 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // per SIMD; one more live value in an epilogue made the allocator give up and settle at 3 (97 + 32 registers), which
 // cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
 // and fits 99-104 registers without spilling.
-__global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
+__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
-  static_assert(DMA == 0 || (PREC == PREC_F32 && (TB == 1 || (TB == 9 && DMA == 3 && KS == 3)) && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)),
+#if RIB_EXP & 2048
+  long long tacc[4] = {0, 0, 0, 0};
+  const long long t_begin = clock64();
+#endif
+  constexpr int DM = DMA & 3;                   // which operands are staged by LDS-DMA
+  constexpr bool WS = (DMA & 4) != 0;           // warp-specialised: 4 consumer waves + 4 loader waves
+  static_assert(DM == 0 || (PREC == PREC_F32 && (TB == 1 || (TB == 9 && DM == 3 && KS == 3)) && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)),
                 "DMA staging: fp32, 32-column path, no fused shortcut; one slice per barrier, or all nine of a chunk with a DMA-staged input tile");
+  static_assert(!WS || (PREC == PREC_F32 && KW == 1 && !AUX && !UPS && NF > 0 && ((TB == 3 && DM == 0) || (TB == 1 && DM == 3))),
+                "warp-specialised loops: fp32, 32-column path, no fused shortcut; register-staged three-slice stages or DMA-staged single slices");
   static_assert(!(DMA & 2) || !PRO, "the input tile can only be staged by DMA when no prologue transforms it on the way into LDS");
   constexpr bool BF16 = G::BF16;                // 16-bit storage, bf16 or half (ST says which)
   constexpr int ST = PREC;
@@ -328,7 +350,8 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
   float* sA = smem;
   float* sB = smem + G::NA * G::SA;
 
-  const int tid = threadIdx.x;
+  const int role = WS ? (int)(threadIdx.x >> 8) : 0;      // warp-specialised: 1 = loader wave
+  const int tid = WS ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   const int lane = tid & 63;
   const int kw = KW == 1 ? 0 : (tid >> 8);      // wave group (in-workgroup K slice)
   const int wave = (tid >> 6) & 3;
@@ -424,7 +447,8 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         const int row = idx / GPRB, c4 = idx % GPRB;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = *reinterpret_cast<const float4*>(wb + w_off(n0 + row, dy * (TB == 4 ? 4 : 3) + t, kc, c4));
+          v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
+                            : *reinterpret_cast<const float4*>(wb + w_off(n0 + row, dy * (TB == 4 ? 4 : 3) + t, kc, c4));
         breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB(buf ^ 1); }
     }
     sA = smem;
-  } else if constexpr (TB == 9 && DMA == 0) {
+  } else if constexpr (TB == 9 && DM == 0) {
     // all nine filter slices of a chunk staged at once; input tile AND filters double-buffered across chunks, so a
     // chunk costs ONE barrier: chunk k+1 is written to the other buffers right after the MFMAs of chunk k (its
     // global loads were in flight during them); whoever is past the barrier of chunk k has finished chunk k-1
@@ -751,31 +775,112 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB3(buf ^ 1); }
     }
     sA = smem;
+  } else if constexpr (TB == 3 && WS) {
+    // ---- warp-specialised: a stage = the three filter slices of one filter row (and, at row 0, the chunk's input tile, double-
+    // buffered).  Loader waves 4-7 run one stage ahead: while the consumer waves 0-3 issue the MFMAs of stage s they commit
+    // stage s + 1 to LDS (filters loaded during stage s - 1, tile prefetched a chunk ahead) and issue the loads of stage s + 2;
+    // ONE barrier per stage for everybody.  The consumers' instruction stream is fragment reads and MFMAs only (the stamps of
+    // tools/probes/igemm_harness.hip: a quarter to a third of a wave's time was staging in the unspecialised loop).
+    const int nst = ((kc_end - kc_begin) / BK) * 3;
+    consumer_stats();
+    if (role) {
+      loadB3(kc_begin, 0);
+      prefetchA(kc_begin);
+      writeA(false);
+      storeB3(0);
+      if (nst > 1) loadB3(kc_begin, 1);
+      if (kc_begin + BK < kc_end) prefetchA(kc_begin + BK);
+      __syncthreads();                                   // stage 0 is in LDS
+      int kc = kc_begin, dy = 0;
+#pragma unroll 1
+      for (int s = 0; s < nst; ++s) {
+        int ndy = dy + 1, nkc = kc;
+        if (ndy == 3) { ndy = 0; nkc = kc + BK; }
+        RIB_TS(ta);
+        if (s + 1 < nst) {
+          storeB3((s + 1) & 1);                          // (the consumers left this buffer at the barrier of stage s)
+          RIB_TS(tb); RIB_TACC(0, ta, tb);
+          if (ndy == 0 && !(RIB_EXP & 2)) {
+            sA = smem + (((nkc - kc_begin) / BK) & 1) * G::SA;
+            writeA(false);
+            if (nkc + BK < kc_end) prefetchA(nkc + BK);
+          }
+          RIB_TS(tc); RIB_TACC(1, tb, tc);
+          int n2dy = ndy + 1, n2kc = nkc;
+          if (n2dy == 3) { n2dy = 0; n2kc = nkc + BK; }
+          if (s + 2 < nst) loadB3(n2kc, n2dy);
+          RIB_TS(td); RIB_TACC(3, tc, td);
+        }
+        RIB_TS(te);
+        __syncthreads();                                 // stage s + 1 is in LDS; the consumers are done with stage s
+        RIB_TS(tf); RIB_TACC(2, te, tf);
+        dy = ndy; kc = nkc;
+      }
+#if RIB_EXP & 2048
+      if ((threadIdx.x & 63) == 0) {      // loader waves: 0 filter store (incl. the wait for its loads), 1 tile commit + prefetch, 2 barrier wait, 3 load issue
+        const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        long long* d = g_igemm_stamps + (((size_t)gridDim.x * gridDim.y * gridDim.z + wg) * 4 + ((threadIdx.x >> 6) & 3)) * 8;
+        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tacc[3]; d[4] = clock64() - t_begin; d[5] = t_begin;
+      }
+#endif
+      return;
+    }
+    {
+      RIB_TS(tp0);
+      __syncthreads();
+      RIB_TS(tp1); RIB_TACC(0, tp0, tp1);      // (stamps: 0 = the consumers' wait for stage 0; 1 = kernel start to here)
+#if RIB_EXP & 2048
+      tacc[1] = tp1 - t_begin;
+#endif
+    }
+    {
+      int c = 0, dy = 0;
+#pragma unroll 1
+      for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        sA = smem + (c & 1) * G::SA;
+        RIB_TS(ta);
+        compute_tap(dy, 0, buf * 3 + 0);
+        compute_tap(dy, 1, buf * 3 + 1);
+        compute_tap(dy, 2, buf * 3 + 2);
+        RIB_TS(tb); RIB_TACC(3, ta, tb);
+        __syncthreads();
+        RIB_TS(tc); RIB_TACC(2, tb, tc);
+        if (++dy == 3) { dy = 0; ++c; }
+      }
+    }
+    sA = smem;
   } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
     consumer_stats();
     int stage = 0;
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
+      RIB_TS(t0);
       __syncthreads();
-      writeA(false);
+      if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
+      RIB_TS(t1); RIB_TACC(0, t0, t1);
 #pragma unroll 1
       for (int dy = 0; dy < 3; ++dy, ++stage) {
         const int buf = stage & 1;
+        RIB_TS(ta);
         storeB3(buf);
         {
           int ndy = dy + 1, nkc = kc;
           if (ndy == 3) { ndy = 0; nkc = kc + BK; }
           if (nkc < kc_end) loadB3(nkc, ndy);
         }
-        if (dy == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+        if (!(RIB_EXP & 2) && dy == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+        RIB_TS(tb); RIB_TACC(1, ta, tb);
         __syncthreads();
+        RIB_TS(tc); RIB_TACC(2, tb, tc);
         compute_tap(dy, 0, buf * 3 + 0);
         compute_tap(dy, 1, buf * 3 + 1);
         compute_tap(dy, 2, buf * 3 + 2);
+        RIB_TS(td); RIB_TACC(3, tc, td);
       }
     }
-  } else if constexpr (DMA != 0) {
+  } else if constexpr (DM != 0) {
     // ---- operand tiles staged by LDS-DMA (see IgemmGeom).  ONE barrier per filter slice and no store phase: behind the
     // barrier of slice t every wave issues the fill of slice t + 1 into the other filter buffer (and, at slice 0, the fill of
     // the next chunk's input tile into the other tile buffer), then runs the MFMAs of slice t over them.  The DMA is inline
@@ -856,6 +961,39 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         st ^= 1;
       }
       sA = smem;
+    } else if constexpr (WS) {
+      // ---- warp-specialised (DMA-staged tile and filters): the loader waves issue every fill - a DMA instruction takes ~250
+      // cycles to issue while the memory pipeline is busy (stamps), time the consumer waves now spend on MFMAs - wait for their own
+      // part to land and meet the consumers at the slice's barrier; same two-buffer protocol as below
+      const int nsl = ((kc_end - kc_begin) / BK) * G::TAPS;
+      if (role) {
+        fillA(0, kc_begin);
+        fillB(0, kc_begin, 0);
+        int kc = kc_begin, tap = 0, abuf = 0;
+#pragma unroll 1
+        for (int s = 0; s < nsl; ++s) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                                 // slice s has landed; the consumers are done with slice s - 1
+          int ntap = tap + 1, nkc = kc;
+          if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
+          if (nkc < kc_end) fillB((s & 1) ^ 1, nkc, ntap);
+          if (tap == 0 && kc + BK < kc_end) fillA(abuf ^ 1, kc + BK);
+          if (ntap == 0) abuf ^= 1;
+          tap = ntap; kc = nkc;
+        }
+        return;
+      }
+      {
+        int tap = 0, abuf = 0;
+#pragma unroll 1
+        for (int s = 0; s < nsl; ++s) {
+          __syncthreads();
+          sA = smem + abuf * G::SA;
+          compute_tap(tap / KS, tap % KS, s & 1);
+          if (++tap == G::TAPS) { tap = 0; abuf ^= 1; }
+        }
+      }
+      sA = smem;
     } else {
     if constexpr (DMA & 2) fillA(0, kc_begin); else prefetchA(kc_begin);
     fillB(0, kc_begin, 0);
@@ -868,8 +1006,11 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
 #pragma unroll 1
       for (int tap = 0; tap < G::TAPS; ++tap, ++stage) {
         const int buf = stage & 1;
+        RIB_TS(ta);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slice `tap` (and, at slice 0, of the chunk's input tile) has landed
+        RIB_TS(tb); RIB_TACC(0, ta, tb);                     // (stamps: 0 = waiting for the own fills here)
         __syncthreads();                                      // ... and everybody's; everybody is done with slice tap - 1
+        RIB_TS(tc); RIB_TACC(2, tb, tc);
         {
           int ntap = tap + 1, nkc = kc;
           if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
@@ -878,8 +1019,10 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
         if (tap == 0 && kc + BK < kc_end) {
           if constexpr (DMA & 2) fillA(abuf ^ 1, kc + BK); else prefetchA(kc + BK);
         }
+        RIB_TS(td); RIB_TACC(1, tc, td);
         if constexpr (DMA & 2) sA = smem + abuf * G::SA;
         compute_tap(tap / KS, tap % KS, buf);
+        RIB_TS(te); RIB_TACC(3, td, te);
       }
       abuf ^= 1;
     }
@@ -936,11 +1079,14 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
   prefetchA(kc_begin);
   consumer_stats();
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
+    RIB_TS(t0);
     __syncthreads();   // every wave is done reading sA / sB of the previous chunk
     if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
+    RIB_TS(t1); RIB_TACC(0, t0, t1);
 #pragma unroll 1
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int buf = tap & 1;
+      RIB_TS(ta);
       storeB(buf);
       {  // prefetch the next filter slice while this tap computes
         int ntap = tap + 1, nkc = kc;
@@ -950,12 +1096,22 @@ __global__ __launch_bounds__(256 * KW, (PREC == 0 && NF == 2 && MF == 1 && !UPS 
       // next input chunk: issued AFTER the filter load so that the in-order vmcnt wait at the
       // next storeB does not have to cover it
       if (!(RIB_EXP & 2) && tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
+      RIB_TS(tb); RIB_TACC(1, ta, tb);
       __syncthreads();
+      RIB_TS(tc); RIB_TACC(2, tb, tc);
       compute_tap(tap / KS, tap % KS, buf);
+      RIB_TS(td); RIB_TACC(3, tc, td);
     }
   }
   }
 
+#if RIB_EXP & 2048
+  if ((threadIdx.x & 63) == 0) {
+    const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    long long* d = g_igemm_stamps + (wg * (256 * KW / 64) + (threadIdx.x >> 6)) * 8;
+    d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tacc[3]; d[4] = clock64() - t_begin; d[5] = t_begin;
+  }
+#endif
   // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----
   if constexpr (AUX && KS == 3 && STRIDE == 1 && !UPS && !SPADE) if (p.x2 != nullptr && split == p.ksplit - 1) {
     const char* x2n = reinterpret_cast<const char*>(p.x2) + (size_t)n * p.Hin * p.Win * p.x2C * ESZ;
