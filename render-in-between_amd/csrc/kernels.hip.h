@@ -312,7 +312,7 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // per SIMD; one more live value in an epilogue made the allocator give up and settle at 3 (97 + 32 registers), which
 // cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
 // and fits 99-104 registers without spilling.
-__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PREC == 0 && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
+__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((PREC == 0 || SPADE) && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
 #if RIB_EXP & 2048
   long long tacc[4] = {0, 0, 0, 0};
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
   constexpr bool N16 = (NF == 0);
   constexpr int NFE = N16 ? 1 : NF;
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(FRW >= 8 && 32 % FRW == 0, "fragment = 32 / FRW rows of FRW pixels; the epilogue's element -> pixel map needs FRW >= 8");
   static_assert(!SPADE || (NF % 2 == 0 && NF > 0) || (NF == 1 && PREC == PREC_F32 && KW == 1), "SPADE needs gamma/beta fragment pairs, or ONE fragment [gamma(16) | beta(16)] (fp32)");
   static_assert(!N16 || (FRW == 16 && WN == 1 && STRIDE == 1 && !UPS && !SPADE && BK % 16 == 0 && PREC == PREC_F32), "16-column path: 8x16-style tiles only, fp32");
   static_assert(!UPS || (STRIDE == 1 && KS == 3 && KW == 1 && (TB == 1 || TB == 4) && NF > 0 && !SPADE), "phase-decomposed upsample conv: 3x3 stride 1, 32-column path");
@@ -1274,8 +1275,24 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
         // the 16 residual reads of a fragment are issued as one batch from clamped (always valid) addresses: inside
         // the bounds-checked store loop below each read sat behind the previous element's store (the compiler
         // cannot reorder a load over a possibly aliasing store): 16 serialised memory round trips per fragment
+        // Element r of the fragment is pixel (oy0 + RY(r), ox0 + RX(r)) with compile-time RY / RX (FRW >= 8: the lane's 4 * lh
+        // never carries into the row), oy0 wave-uniform and ox0 = tx0 + 4 * lh.  Where the fragment lies inside the image
+        // (`full`: every launch of the frame except ragged sizes) every address below is ONE per-lane base plus a scalar offset
+        // per element - the generic form spent ~10 vector instructions per element, quarter-rate 32-bit multiplies among them,
+        // on ((n * H + oy) * W + ox) * C: a third of the kernel on the small-K layers (ISA count, DESIGN round 3).
+        const int oy0 = ty0 + (__builtin_amdgcn_readfirstlane(wm) * MF + mf) * G::FRH, ox0 = tx0 + 4 * lh;
+        const bool full = !UPS && oy0 + G::FRH <= p.Hout && tx0 + FRW <= p.Wout;      // (uniform)
         float rv[16];
-        if (p.res) {
+        if (p.res && full) {
+          const int sh = p.res_ups ? 1 : 0;
+          const size_t rrow = (size_t)(p.Wout >> sh) * p.resC;
+          const size_t rbase = (((size_t)n * (p.Hout >> sh) + (oy0 >> sh)) * (p.Wout >> sh) + (ox0 >> sh)) * p.resC + min(col, p.resC - 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
+            rv[r] = ld_act<ST>(p.res, rbase + (size_t)(RY >> sh) * rrow + (size_t)(RX >> sh) * p.resC);
+          }
+        } else if (p.res) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1319,14 +1336,17 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
           }
         }
         unsigned okm = 0;
+        if (full) okm = cvalid ? 0xffffu : 0u;
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
-          int ox = tx0 + row % FRW;
-          if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }   // phase ph of source pixel (oy, ox)
-          const bool ok = cvalid && oy < p.Hout && ox < p.Wout;
-          okm |= ok ? (1u << r) : 0u;
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+            int ox = tx0 + row % FRW;
+            if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }   // phase ph of source pixel (oy, ox)
+            const bool ok = cvalid && oy < p.Hout && ox < p.Wout;
+            okm |= ok ? (1u << r) : 0u;
+          }
         }
         if (ph == 0 && mf == 0) pv = vv[0];
 #pragma unroll
@@ -1335,6 +1355,27 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
           d1 += d;
           d2 += d * d;
         }
+        if (full) {
+          if (cvalid) {
+            const size_t yrow = (size_t)p.Wout * p.yC;
+            const size_t ybase = (((size_t)ny * p.Hout + oy0) * p.Wout + ox0) * p.yC + yoff + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
+              const size_t yi = ybase + (size_t)RY * yrow + (size_t)RX * p.yC;
+              if constexpr (BF16) { if (p.y_f32) p.y[yi] = vv[r]; else st_act<ST>(p.y, yi, vv[r]); }
+              else p.y[yi] = vv[r];
+            }
+            if (p.y_nchw) {
+              const size_t nbase = (((size_t)n * p.Cout + col) * p.Hout + oy0) * p.Wout + ox0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
+                p.y_nchw[nbase + (size_t)RY * p.Wout + RX] = BF16 ? vf[r] : vv[r];
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1357,13 +1398,16 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
             if (okm & (1u << r)) p.y_nchw[(((size_t)n * p.Cout + col) * p.Hout + oy) * p.Wout + ox] = BF16 ? vf[r] : vv[r];
           }
         }
+        }
       }
       if (p.stat_part) {
         int cnt = 0;      // valid elements of this lane in this column fragment (coordinates only: nothing kept live for it)
 #pragma unroll
         for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf)
+          for (int mf = 0; mf < MF; ++mf) {
+            const int oy0 = ty0 + (__builtin_amdgcn_readfirstlane(wm) * MF + mf) * G::FRH;
+            if (!UPS && oy0 + G::FRH <= p.Hout && tx0 + FRW <= p.Wout) { cnt += cvalid ? 16 : 0; continue; }      // (a full fragment)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1372,6 +1416,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
               if (UPS) { oy = 2 * oy + (ph >> 1); ox = 2 * ox + (ph & 1); }
               cnt += (cvalid && oy < p.Hout && ox < p.Wout) ? 1 : 0;
             }
+          }
         const double k = (double)cnt, pd = (double)pv;
         const double s1 = k * pd + (double)d1;
         const double s2 = (k * pd + 2.0 * (double)d1) * pd + (double)d2;
@@ -1420,15 +1465,29 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
     const int Hm = p.xm_ups ? p.Hout / 2 : p.Hout, Wm = p.xm_ups ? p.Wout / 2 : p.Wout;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
+      // (a fragment inside the image: one per-lane base + a scalar offset per element, as in the convolution epilogue; this
+      // lane's elements are r = 8 hb + k: pixel row oy0 + (16 hb) / FRW + RY(k), column ox0 + RX(k))
+      const int oy0 = ty0 + (__builtin_amdgcn_readfirstlane(wm) * MF + mf) * G::FRH;
+      const bool full = oy0 + G::FRH <= p.Hout && tx0 + FRW <= p.Wout;      // (uniform)
+      const int oyl = oy0 + (16 * hb) / FRW, oxl = tx0 + 4 * lh;
+      const int s = p.xm_ups ? 1 : 0;
+      const size_t xrow = (size_t)Wm * p.xmC, yrow = (size_t)p.Wout * p.C;
+      const size_t xbase = (((size_t)n * Hm + (oyl >> s)) * Wm + (oxl >> s)) * p.xmC + (vvalid ? c : 0);
+      const size_t ybase = (((size_t)n * p.Hout + oyl) * p.Wout + oxl) * p.C + c;
       float xr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int r = hb * 8 + k;
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
-        const int ox = min(tx0 + row % FRW, p.Wout - 1);
-        const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-        xr[k] = ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+        if (full) {
+          const int RY = (8 * (k >> 2)) / FRW, RX = (8 * (k >> 2)) % FRW + (k & 3);
+          xr[k] = ld_act<ST>(p.xm, xbase + (size_t)(RY >> s) * xrow + (size_t)(RX >> s) * p.xmC);
+        } else {
+          const int r = hb * 8 + k;
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
+          const int ox = min(tx0 + row % FRW, p.Wout - 1);
+          const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
+          xr[k] = ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1436,14 +1495,17 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
         const float olo = __shfl_xor(lo, 16), ohi = __shfl_xor(hi, 16);
         const float gamma = (hb ? ohi : lo) + bg;               // gamma lanes own row k, beta lanes fetch row 8 + k's gamma
         const float beta = (hb ? hi : olo) + bb;
-        const int r = hb * 8 + k;
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
-        const int ox = tx0 + row % FRW;
-        if (vvalid && oy < p.Hout && ox < p.Wout) {
-          float o = (xr[k] * sc + sh) * (1.f + gamma) + beta;
-          o = apply_act(o, act);
-          st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
+        float o = (xr[k] * sc + sh) * (1.f + gamma) + beta;
+        o = apply_act(o, act);
+        if (full) {
+          const int RY = (8 * (k >> 2)) / FRW, RX = (8 * (k >> 2)) % FRW + (k & 3);
+          if (vvalid) st_act<ST>(yout, ybase + (size_t)RY * yrow + (size_t)RX * p.C, o);
+        } else {
+          const int r = hb * 8 + k;
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = ty0 + (wm * MF + mf) * G::FRH + row / FRW;
+          const int ox = tx0 + row % FRW;
+          if (vvalid && oy < p.Hout && ox < p.Wout) st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
         }
       }
     }
@@ -1469,7 +1531,33 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
       for (int mf = 0; mf < MF; ++mf) {
         // all 16 reads of the normalised tensor first (clamped, always valid addresses), then the modulation and
         // the stores: one memory round trip per fragment instead of 16 serialised load -> store pairs
+        // (a fragment inside the image: one per-lane base + a scalar offset per element, as in the convolution epilogue)
+        const int oy0 = ty0 + (__builtin_amdgcn_readfirstlane(wm) * MF + mf) * G::FRH, ox0 = tx0 + 4 * lh;
+        const bool full = oy0 + G::FRH <= p.Hout && tx0 + FRW <= p.Wout;      // (uniform)
         float xr[16];
+        if (full) {
+          const int s = p.xm_ups ? 1 : 0;
+          const size_t xrow = (size_t)Wm * p.xmC;
+          const size_t xbase = (((size_t)n * Hm + (oy0 >> s)) * Wm + (ox0 >> s)) * p.xmC + (vvalid ? c : 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
+            xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<ST>(p.xm, xbase + (size_t)(RY >> s) * xrow + (size_t)(RX >> s) * p.xmC);
+          }
+          if (vvalid) {
+            const size_t yrow = (size_t)p.Wout * p.C;
+            const size_t ybase = (((size_t)n * p.Hout + oy0) * p.Wout + ox0) * p.C + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
+              const float gamma = acc[mf][2 * q][r] + bg;
+              const float beta = acc[mf][2 * q + 1][r] + bb;
+              float o = (xr[r] * sc + sh) * (1.f + gamma) + beta;
+              o = apply_act(o, act);
+              if (!(RIB_EXP & 16) || o == 123.456f) st_act<ST>(yout, ybase + (size_t)RY * yrow + (size_t)RX * p.C, o);
+            }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1491,6 +1579,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : (PR
             o = apply_act(o, act);
             if (!(RIB_EXP & 16) || o == 123.456f) st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
           }
+        }
         }
       }
     }
