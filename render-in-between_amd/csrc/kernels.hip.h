@@ -311,8 +311,9 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // two column fragments per wave (NF = 2: 32 accumulator registers) sit exactly on the 128-register boundary of 4 waves
 // per SIMD; one more live value in an epilogue made the allocator give up and settle at 3 (97 + 32 registers), which
 // cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
-// and fits 99-104 registers without spilling.
-__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((PREC == 0 || SPADE) && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : 1)) void k_igemm(const IgemmParams p) {
+// and fits 99-104 registers without spilling.  (Likewise the 16-bit 8x16 BN32 BK16 generic variant: 81 + 16 registers is one
+// over the boundary of 5 waves.)
+__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((PREC == 0 || SPADE) && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : ((PREC != 0 && NF == 1 && MF == 1 && BK == 16 && KS == 3 && !UPS && KW == 1 && TB == 1) ? 5 : 1))) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
 #if RIB_EXP & 2048
   long long tacc[4] = {0, 0, 0, 0};
@@ -480,13 +481,19 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
     iy = iy0 + ly; ix = ix0 + lx;
     return idx < total4 && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
   };
+  // element offset of slot i's 16 bytes at chunk 0, or -1 for a slot outside the image (zero padding) or beyond the tile: the
+  // pixel decomposition, the bounds tests and the multiplies are done once, not per chunk in prefetchA AND in writeA
+  int aslot[NA4];
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) {
+    int pix, iy, ix;
+    aslot[i] = slot_inb(i, pix, iy, ix) ? (iy * p.Win + ix) * p.xC + ac4 * EPS : -1;      // < 2^31 elements per sample (checked by the host)
+  }
   auto prefetchA = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
-      int pix, iy, ix;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (slot_inb(i, pix, iy, ix))
-        v = *reinterpret_cast<const float4*>(xn + (size_t)(unsigned)((iy * p.Win + ix) * p.xC + kc + ac4 * EPS) * ESZ);   // < 2^31 elements per sample (checked by the host)
+      if (aslot[i] >= 0) v = *reinterpret_cast<const float4*>(xn + (size_t)(unsigned)(aslot[i] + kc) * ESZ);
       areg[i] = v;
     }
     if constexpr (PRO) {
@@ -504,8 +511,8 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
   auto writeA = [&](bool raw) {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
-      int pix, iy, ix;
-      const bool inb = slot_inb(i, pix, iy, ix);
+      const int pix = (tid + i * NT) / GPR;
+      const bool inb = aslot[i] >= 0;
       float4 v = areg[i];
       if constexpr (PRO) {
         const bool aff = !raw && p.pro_scale, lr = !raw && p.pro_lrelu;
