@@ -1621,10 +1621,14 @@ struct GemmDmaParams {
   int modB;               // 0: one B for every z
 };
 
-template <int WM, int WN, int NF>
+// ST = ST_BF16 / ST_F16: A and B hold 16-bit elements (lda, K, sA, sB in elements), a 128-byte row chunk is 64 of them, a
+// lane's 16-byte slot feeds ONE v_mfma_f32_32x32x16 (k = 8 per lane half) where it feeds four fp32 MFMAs; C stays fp32 (the
+// level slab k_spade_modulate reads).  Same tile, same swizzle, same two stages.
+template <int WM, int WN, int NF, int ST = ST_F32>
 __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int BM = 32 * WM, BN = 32 * NF * WN, BK = 32;
+  constexpr int BM = 32 * WM, BN = 32 * NF * WN, BK = 32;      // BK: 4-byte words of a row chunk (128 bytes)
+  constexpr int EPW = ST == ST_F32 ? 1 : 2;                    // elements per 4-byte word
   constexpr int STAGE = (BM + BN) * BK;              // floats
   constexpr int NFILL = (BM + BN) / 32;              // DMA instructions per wave and chunk (8 rows each)
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
@@ -1633,14 +1637,15 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
-  const float* A = p.A + (size_t)z * p.sA;
-  const float* B = p.B + (size_t)(p.modB ? z % p.modB : 0) * p.sB;
+  // (4-byte word pointers; element strides are even in the 16-bit modes: padded channel counts)
+  const float* A = p.A + (size_t)z * p.sA / EPW;
+  const float* B = p.B + (size_t)(p.modB ? z % p.modB : 0) * p.sB / EPW;
   f32x16 acc[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-  const int nch = p.K / BK;
+  const int nch = p.K / (BK * EPW);
   typedef __attribute__((address_space(3))) void lds_void;
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
   // this lane's source rows: fill j of a wave covers tile rows [wave * 8 + 32 j, + 8) of the stacked (A rows | B rows) tile;
@@ -1652,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
     const bool isA = 32 * j < BM;                                     // (BM is a multiple of 32: a fill never straddles A | B)
     const int row = isA ? trow : trow - BM;
     const int ls = (lane & 7) ^ ((row >> 1) & 7);
-    src[j] = isA ? A + (size_t)min(m0 + row, p.M - 1) * p.lda + ls * 4 : B + (size_t)min(n0 + row, p.N - 1) * p.K + ls * 4;
+    src[j] = isA ? A + (size_t)min(m0 + row, p.M - 1) * (p.lda / EPW) + ls * 4 : B + (size_t)min(n0 + row, p.N - 1) * (p.K / EPW) + ls * 4;
   }
   auto fill = [&](int st, int kc) {
 #pragma unroll
@@ -1682,10 +1687,16 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
       }
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nf].x, acc[nf], 0, 0, 0);
-        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nf].y, acc[nf], 0, 0, 0);
-        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nf].z, acc[nf], 0, 0, 0);
-        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nf].w, acc[nf], 0, 0, 0);
+        if constexpr (ST == ST_F32) {
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nf].x, acc[nf], 0, 0, 0);
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nf].y, acc[nf], 0, 0, 0);
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nf].z, acc[nf], 0, 0, 0);
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nf].w, acc[nf], 0, 0, 0);
+        } else if constexpr (ST == ST_F16) {
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b[nf]), acc[nf], 0, 0, 0);
+        } else {
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b[nf]), acc[nf], 0, 0, 0);
+        }
       }
     }
   }

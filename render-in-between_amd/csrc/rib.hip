@@ -351,9 +351,10 @@ inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
 }
 
 inline Variant dmak_variant(Variant v) { v.DMAK = 1; return v; }
-inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn) {
-  Variant v{0, WM, WN, 1, NF, 32, 1, 1, false, false, nullptr};
+inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn, int prec = PREC_F32) {
+  Variant v{0, WM, WN, 1, NF, prec == PREC_F32 ? 32 : 64, 1, 1, false, false, nullptr};      // BK: elements of a 128-byte row chunk
   v.gfn = fn;
+  v.BF16 = prec;
   return v;
 }
 const Variant kVariants[] = {
@@ -361,6 +362,11 @@ const Variant kVariants[] = {
     // k_gemm_dma tiles (instantiated in this translation unit): 128x64, 64x64, 64x128, 128x128, 128x32
     dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2>), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1>), dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2>),
     dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4>), dma_variant(4, 1, 1, &k_gemm_dma<4, 1, 1>),
+    // ... and their 16-bit storage twins (the condition-level GEMMs of the bf16 / half modes)
+    dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2, ST_BF16>, PREC_BF16), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1, ST_BF16>, PREC_BF16),
+    dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2, ST_BF16>, PREC_BF16), dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4, ST_BF16>, PREC_BF16),
+    dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2, ST_F16>, PREC_F16), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1, ST_F16>, PREC_F16),
+    dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2, ST_F16>, PREC_F16), dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4, ST_F16>, PREC_F16),
 };
 const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -427,13 +433,13 @@ Choice choose_variant_dt(int bf16, int stride, int ks, bool ups, bool spade, int
 
 // default k_gemm_dma tile of a Z x [M x N x K] problem: the largest tile that still gives two workgroups per CU, else the
 // tile with the most workgroups (RIB_NO_DMA=1: none - the callers fall back to k_igemm's 1x1 variants)
-const Variant* pick_gemm_dma(int prec, long Z, int M, int N) {
+const Variant* pick_gemm_dma(int prec, long Z, int M, int N, int K) {
   static const bool off = getenv("RIB_NO_DMA") != nullptr;
-  if (off || prec != PREC_F32) return nullptr;
+  if (off || K % (prec == PREC_F32 ? 32 : 64) != 0) return nullptr;
   const Variant* best = nullptr; long best_area = 0, best_wgs = 0;
   for (int i = 0; i < kNumVariants; ++i) {
     const Variant& v = kVariants[i];
-    if (!v.dma()) continue;
+    if (!v.dma() || v.BF16 != prec) continue;
     const long wgs = Z * ((M + v.BM() - 1) / v.BM()) * ((N + v.BN() - 1) / v.BN());
     const long area = (long)v.BM() * v.BN();
     const bool full = wgs >= 512, bfull = best_wgs >= 512;
@@ -1267,7 +1273,7 @@ struct Builder {
     {   // the 16 / 36 GEMMs as one 1x1 "convolution" of NP*B samples of a tilesY x tilesX image, one filter set per position
       // k_gemm_dma (operands staged by LDS-DMA) unless a tuned choice names a k_igemm 1x1 variant; TB_() decides as for every choice
       Choice ch;
-      ch.v = pick_gemm_dma(h->prec(), (long)TB_() * NP, ntiles, c.coutp);
+      ch.v = pick_gemm_dma(h->prec(), (long)TB_() * NP, ntiles, c.coutp, c.cinp);
       if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, c.coutp, TB_() * NP, tilesY, tilesX, c.cinp, false, 0, false);
       auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, gname.c_str()));
       if (it != h->choices.end()) {
@@ -1361,7 +1367,7 @@ struct Builder {
     const SpadeGroup& first = h->spades[it->second[0]];
     const std::string name = fmt("cond_%d.gammabeta", level);
     Choice ch;
-    ch.v = pick_gemm_dma(h->prec(), B, cond.H * cond.W, N);
+    ch.v = pick_gemm_dma(h->prec(), B, cond.H * cond.W, N, cond.Cp);
     if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, N, B, cond.H, cond.W, cond.Cp, false);
     {
       auto ct = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, name.c_str()));
@@ -1385,7 +1391,7 @@ struct Builder {
       memset(&g, 0, sizeof g);
       g.M = cond.H * cond.W; g.N = N; g.K = cond.Cp; g.lda = cond.Cp; g.ldc = N;
       g.sA = (size_t)g.M * cond.Cp; g.sB = 0; g.sC = (size_t)g.M * N; g.modB = 0;
-      op.g_a = WS(cond.off); op.g_b = WT(first.w_off); op.g_c = WS(slab_off);
+      op.g_a = WS(cond.off); op.g_b = WT(h->mc16() ? first.w16_off : first.w_off); op.g_c = WS(slab_off);
       op.grid = dim3((g.M + v->BM() - 1) / v->BM(), (N + v->BN() - 1) / v->BN(), B);
       P->flops[RIB_KC_SPADE] += fl;
       push(op);
