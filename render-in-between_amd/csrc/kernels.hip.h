@@ -1737,19 +1737,25 @@ struct FinalizeParams {
   int g_stride, pair_merge, pair_off;
 };
 
+// CH = 16: block = 16 channels x 64 tile slices, grid (Cs / 16, B).  CH = 4 (launches with more than 512 partials per channel: the
+// full-resolution layers): 4 channels x 256 slices, grid (Cs / 4, B) - with 32 channels the 16-channel shape runs on TWO CUs and
+// every thread walks 16-32 rows (9.6 us for 2048 partials in the bf16 plan); four times the workgroups and a quarter of the walk.
+// The sums are fixed-order either way; the two shapes associate them differently (fp64: not visible in the fp32 scale / shift).
+template <int CH>
 __global__ __launch_bounds__(1024) void k_stats_finalize(const FinalizeParams p) {
-  // block = 16 channels x 64 tile slices: short dependent-load chains even for 2048 tiles
-  __shared__ double red[2][64][16];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  static_assert(CH == 16 || CH == 4, "16 channels x 64 slices or 4 channels x 256 slices");
+  constexpr int SL = 1024 / CH;
+  __shared__ double red[2][16][CH];
+  const int cl = threadIdx.x % CH, sl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
   const int n = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
-  if (c < p.Cs) stats_from_partials(p.part + (size_t)n * p.tiles * 2 * p.Cs, p.tiles, p.Cs, c, sl, 64, a1, a2);
-  // fixed-shape reduction over the 64 slices: the 4 slices of a wavefront with shuffles, then the 16
+  if (c < p.Cs) stats_from_partials(p.part + (size_t)n * p.tiles * 2 * p.Cs, p.tiles, p.Cs, c, sl, SL, a1, a2);
+  // fixed-shape reduction over the slices: the slices of a wavefront with shuffles, then the 16
   // wavefront sums in order by one thread per channel (one barrier; an LDS tree needed seven)
-  a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-  a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
-  if ((threadIdx.x & 63) < 16) { red[0][threadIdx.x >> 6][cl] = a1; red[1][threadIdx.x >> 6][cl] = a2; }
+#pragma unroll
+  for (int off = CH; off < 64; off <<= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+  if ((threadIdx.x & 63) < CH) { red[0][threadIdx.x >> 6][cl] = a1; red[1][threadIdx.x >> 6][cl] = a2; }
   __syncthreads();
   if (sl == 0) {
     double t1 = 0.0, t2 = 0.0;

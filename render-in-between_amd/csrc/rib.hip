@@ -2093,7 +2093,8 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         FinalizeParams p = op.fp;
         p.part = R.get<const double>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
         p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
-        hipLaunchKernelGGL(k_stats_finalize, op.grid, dim3(1024), 0, st, p);
+        if (p.tiles > 512) hipLaunchKernelGGL(k_stats_finalize<4>, dim3((p.Cs + 3) / 4, op.grid.y, op.grid.z), dim3(1024), 0, st, p);
+        else hipLaunchKernelGGL(k_stats_finalize<16>, op.grid, dim3(1024), 0, st, p);
       } break;
       case OP_MODULATE: {
         ModulateParams p = op.mp;
