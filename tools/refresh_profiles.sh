@@ -40,7 +40,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -o bench 
 cp $OUT/prof_bf16/bench_kernel_stats.csv $OUT/${TAG}_bench_bf16_kernel_stats.csv
 echo "[refresh] multi-rank rehearsal on one GPU (2 ranks share device 0, gloo instead of RCCL): BASELINE config 4 shape"
 cd $ROOT
-RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --mode clips --steps 3 --warmup 1 > $OUT/${TAG}_clips_2ranks_1gpu.json 2> $OUT/${TAG}_clips_2ranks_1gpu.err
+RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --mode clips --steps 3 --warmup 1 2> $OUT/${TAG}_clips_2ranks_1gpu.err | grep '^{' > $OUT/${TAG}_clips_2ranks_1gpu.json      # (gloo prints its connection banner on stdout)
 cd /tmp
 echo "[refresh] k_warp: timing + FETCH / WRITE counters"
 python3 $ROOT/tools/warp_bench.py --time --out $OUT/${TAG}_warp.json > $OUT/${TAG}_warp.log 2>&1
