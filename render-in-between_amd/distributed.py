@@ -92,6 +92,12 @@ def init_process_group(backend: str = None, device: torch.device = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    # RCCL writes its debug output to STDOUT; with NCCL_DEBUG=VERSION (exported on the GPU boxes) that is a five-line banner at
+    # the first communicator, and NCCL_DEBUG_FILE does not move it.  stdout belongs to the callers' results (bench.py: ONE
+    # JSON line), so the banner level is lowered to warnings-only; any other level the user set stays, in a file of its own
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     kw = {}
     if backend == "nccl" and device is not None and torch.device(device).type == "cuda":
         kw["device_id"] = torch.device(device)

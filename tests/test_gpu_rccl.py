@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_rccl_world_of_one_runs_the_collectives_of_the_multi_gpu_path():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", NCCL_DEBUG="VERSION")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rccl smoke ok: backend nccl" in r.stdout, r.stdout[-2000:]
+    # stdout is the callers' result channel (bench.py prints ONE JSON line): RCCL's version banner (NCCL_DEBUG=VERSION is
+    # exported on the GPU boxes) must not land there
+    assert "RCCL version" not in r.stdout and len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]
