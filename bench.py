@@ -46,7 +46,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--size", type=int, default=512, help="square frames: shorthand for --height S --width S")
+    ap.add_argument("--height", type=int, default=0, help="frame height (with --width), e.g. the reference's default working "
+                                                          "resolution --height 320 --width 480 (PGNR/configs/HSM.yaml:192-193)")
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--mode", choices=("frame", "chain", "clips"), default="frame",
                     help="frame: one forward+blend per step (BASELINE configs[1], the default); chain: one autoregressive "
@@ -115,7 +118,7 @@ def main():
 
     cfg = rib.hsm_gen_config()
     spec = rib.GenSpec.from_cfg(cfg)
-    H = W = args.size
+    H, W = (args.height or args.size), (args.width or args.size)
     B = args.batch
     G = rib.Generator(cfg, device=dev, compute_dtype=args.dtype).eval()
     sd = None

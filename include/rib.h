@@ -11,8 +11,12 @@
  * and its launch plans.  A handle is bound to one device, is single-stream and not re-entrant
  * (one handle per GPU / process).  Every launch of an entry point is enqueued, in order, on the caller's
  * stream; the handle owns no streams or events.
- * No entry point synchronises the device except rib_finalize_weights(), rib_read_tap() and
- * rib_profile_collect().
+ * Synchronisation: rib_finalize_weights(), rib_read_tap() and rib_profile_collect() synchronise; rib_import_weights()
+ * waits for its stream once (it reads the blob's 64-byte header back before accepting it); and the FIRST call that
+ * needs the launch plan of a new (B,H,W) - rib_workspace_bytes / rib_forward / rib_chain / the introspection calls -
+ * may allocate device memory for Winograd-domain filter sets and synchronise the device while it computes them
+ * (one-time work per shape; query rib_workspace_bytes() up front to keep it out of a timed or captured region).
+ * Steady-state calls of every other entry point only enqueue.
  *
  * Tensors at the boundary are dense fp32 NCHW on the handle's device, exactly what the reference
  * generator takes and returns (PGNR/models/evaluator.py:250-255).
@@ -211,6 +215,14 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
 int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label,
                 const float* img_fake, const float* img_prev, float* img, float* mask, void* workspace,
                 size_t workspace_bytes, int iters, void* hip_stream, double* usec);
+
+/* ---- build identity (no reference counterpart: the reference is interpreted Python).  A static string
+ *   "librib stamp=<lib> shards=<s0>,...,<s7> consistent=<0|1> variants=<n> compiler=<...>"
+ * where <lib> is the content hash (csrc/build.py: sha256 over rib.hip, kernels.hip.h, raster.hip.h, variants.def,
+ * variants.hip.h, igemm_shard.hip, include/rib.h + flags + compiler version) rib.o was compiled with and <si> the hash
+ * shard object i carries; consistent=1 when all eight shard objects carry the hash rib.o expected of them.  bench.py
+ * prints it in its JSON line; tests/test_native_host.py compares it with the hashes of the tracked tree. ---- */
+const char* rib_build_info(void);
 
 /* ---- host-only debugging (CPU tests): rib_create(cfg, device = -1, ..) builds a handle that owns
  * no device memory; it supports the tensor inventory, rib_set_tensor / rib_finalize_weights (the

@@ -60,6 +60,8 @@ typedef struct {
 int ribm_create(const ribm_config* cfg, int device, ribm_handle** out);
 void ribm_destroy(ribm_handle* h);
 const char* ribm_last_error(const ribm_handle* h);   /* h may be NULL: last failed ribm_create of this thread */
+/* "rib-stamp motion <hash>": content hash of motion.hip + this header + flags + compiler (csrc/build.py), as rib_build_info() */
+const char* ribm_build_info(void);
 
 /* ---- weights: replaces load_state_dict(net, path) (HMM/utils/utils.py:66-80: strict) ----
  * The caller hands over the raw state-dict tensors by their reference names

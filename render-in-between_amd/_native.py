@@ -77,6 +77,7 @@ SIGNATURES = {
     "rib_debug_conv_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "rib_debug_spade_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "rib_debug_launch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "rib_build_info": (C.c_char_p, []),
 }
 
 
@@ -100,6 +101,15 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def build_info():
+    """{'stamp': <lib hash>, 'shards': [8 hashes], 'consistent': bool, 'variants': int, 'raw': str} of the loaded library
+    (rib_build_info, include/rib.h; the hashes are csrc/build.py's content hashes of the sources)."""
+    raw = lib().rib_build_info().decode()
+    kv = dict(tok.split("=", 1) for tok in raw.split(" compiler=")[0].split()[1:])
+    return {"stamp": kv["stamp"], "shards": kv["shards"].split(","), "consistent": kv["consistent"] == "1",
+            "variants": int(kv["variants"]), "raw": raw}
 
 
 def check(handle, rc):

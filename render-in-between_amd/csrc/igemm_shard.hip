@@ -66,6 +66,15 @@
 #define RIB_VSD(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VSD(RIB_F_TOUCH, __VA_ARGS__))
 #define RIB_VD9(sec, ...) RIB_CAT(RIB_ON_, sec)(RIB_I_VD9(RIB_F_TOUCH, __VA_ARGS__))
 
+#ifndef RIB_BUILD_STAMP
+#error "compile through csrc/build.py (-DRIB_BUILD_STAMP: content hash of this object's sources, see build.py)"
+#endif
+#define RIB_STR_(x) #x
+#define RIB_STR(x) RIB_STR_(x)
+// "rib-stamp shard<s> <hash>": what rib_build_info() reports for this object and what build.py looks for in it
+extern "C" __attribute__((used, visibility("hidden"))) const char RIB_CAT(rib_stamp_section_, RIB_SECTION)[] =
+    "rib-stamp shard" RIB_STR(RIB_SECTION) " " RIB_BUILD_STAMP;
+
 typedef void (*IgemmFn)(const rib::IgemmParams);
 extern "C" __attribute__((used, visibility("hidden"))) IgemmFn const RIB_CAT(rib_igemm_section_, RIB_SECTION)[] = {
 #include "variants.def"

@@ -23,9 +23,6 @@
 #ifndef RIB_UPS_ROLL
 #define RIB_UPS_ROLL 0   // phase-decomposed upsample conv: 0 = 16 steps fully unrolled, 1 = taps of a phase rolled
 #endif
-#ifndef RIB_EXP
-#define RIB_EXP 0   // elimination switches for tools/probes/igemm_harness.hip; 0 in the product build
-#endif
 
 namespace rib {
 
@@ -217,10 +214,6 @@ __device__ __forceinline__ void scale_shift_of(double s1, double s2, float inv_c
 // fp32 storage, operands split into three bf16 terms, six bf16 MFMAs per step - never beat fp32 once the deep layers ran
 // in the Winograd domain and was retired in round 3.)
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };      // = ST_F32 / ST_BF16 / ST_F16
-// DMA bit 2 (value 4, "WS"): warp-specialised workgroup of 8 waves - waves 4-7 only stage operands (global -> registers -> LDS,
-// or the DMA fills), waves 0-3 only read fragments and issue MFMAs; see the WS loops in k_igemm.  EXPERIMENT: instantiated by
-// tools/probes/igemm_harness.hip only (bit-identical results, no gain: profiles/r03_igemm_ws_probe.txt, DESIGN "Round 3");
-// no variant of the library uses it.
 // DMA (round 3): bit 0 = the filter slices, bit 1 = the input tile are staged by LDS-DMA (global_load_lds_dwordx4: no staging
 // registers, no ds_write) instead of global -> registers -> LDS.  A DMA instruction lands 64 consecutive 16-byte slots, so the
 // rows of a DMA-staged tile are NOT padded; the 16-byte slot of a row is XOR-swizzled instead (swz below), which is
@@ -269,7 +262,7 @@ struct IgemmGeom {
   static constexpr int SRED = WM * BN * 4;     // floats: [WM][BN][2] fp64 statistics partials
   static constexpr int SKW = KW > 1 ? (NF == 0 ? 1 : NF) * MF * 16 * 256 : 0;   // one wave group's accumulators
   // TB = 9 (3x3) and TB = 2 (1x1: "chunk pairs") also double-buffer the input tile: one barrier per chunk
-  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2) || (DMA & 2) || (DMA & 4)) ? 2 : 1;      // (DMA & 4: loader waves write the next chunk's tile)
+  static constexpr int NA = (TB == 9 || (KS == 1 && TB == 2) || (DMA & 2)) ? 2 : 1;
   static constexpr int TBB = (KS == 1 && TB == 2) ? 1 : TB;   // filter slices per buffer
   static constexpr int SMEM0 = NA * SA + 2 * TBB * SB > SRED ? NA * SA + 2 * TBB * SB : SRED;
   static constexpr int SMEM = SMEM0 > SKW ? SMEM0 : SKW;
@@ -295,16 +288,6 @@ struct IgemmGeom {
 // row -1 / H is exactly where the upsampled row -1 / 2H falls).  A workgroup owns a TH x TW tile of
 // SOURCE pixels and keeps four accumulator sets, one per phase; filter slice t = phase*4 + a*2 + b
 // multiplies the shifted window (py+a, px+b) of the ordinary 3x3 halo tile of the source.
-#if RIB_EXP & 2048
-// tools/probes/igemm_harness.hip: where a wave's time goes in the main loop.  [workgroup * waves + wave][4] cycles:
-// 0 chunk head (barrier + input-tile commit), 1 filter store / fill issue, 2 waiting at the slice barrier, 3 the MFMA section
-__device__ long long* g_igemm_stamps;
-#define RIB_TS(v) const long long v = clock64()
-#define RIB_TACC(i, a, b) tacc[i] += (b) - (a)
-#else
-#define RIB_TS(v) do { } while (0)
-#define RIB_TACC(i, a, b) do { } while (0)
-#endif
 template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, bool UPS, bool SPADE, int PREC = 0,
           bool AUX = true, bool PRO = true, int KW = 1, int TB = 1, int DMA = 0>
 // Second launch bound = minimum waves per SIMD the register allocator must leave room for.  The fp32 variants with
@@ -313,18 +296,11 @@ template <int FRW, int WM, int WN, int MF, int NF, int BK, int STRIDE, int KS, b
 // cost the launches using them 5-20 % (tools/occupancy_diff.py).  With the bound it keeps the accumulators in VGPRs
 // and fits 99-104 registers without spilling.  (Likewise the 16-bit 8x16 BN32 BK16 generic variant: 81 + 16 registers is one
 // over the boundary of 5 waves.)
-__global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((PREC == 0 || SPADE) && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : ((PREC != 0 && NF == 1 && MF == 1 && BK == 16 && KS == 3 && !UPS && KW == 1 && TB == 1) ? 5 : 1))) void k_igemm(const IgemmParams p) {
+__global__ __launch_bounds__(256 * KW, ((PREC == 0 || SPADE) && NF == 2 && MF == 1 && !UPS && KW == 1) ? 4 : ((PREC == 0 && UPS && MF * NF == 1 && KW == 1) ? 2 : ((PREC != 0 && NF == 1 && MF == 1 && BK == 16 && KS == 3 && !UPS && KW == 1 && TB == 1) ? 5 : 1))) void k_igemm(const IgemmParams p) {
   typedef IgemmGeom<FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, KW, TB, PREC, DMA> G;
-#if RIB_EXP & 2048
-  long long tacc[4] = {0, 0, 0, 0};
-  const long long t_begin = clock64();
-#endif
   constexpr int DM = DMA & 3;                   // which operands are staged by LDS-DMA
-  constexpr bool WS = (DMA & 4) != 0;           // warp-specialised: 4 consumer waves + 4 loader waves
   static_assert(DM == 0 || (PREC == PREC_F32 && (TB == 1 || (TB == 9 && DM == 3 && KS == 3)) && KW == 1 && !AUX && NF > 0 && !UPS && (DMA & 1)),
                 "DMA staging: fp32, 32-column path, no fused shortcut; one slice per barrier, or all nine of a chunk with a DMA-staged input tile");
-  static_assert(!WS || (PREC == PREC_F32 && KW == 1 && !AUX && !UPS && NF > 0 && ((TB == 3 && DM == 0) || (TB == 1 && DM == 3))),
-                "warp-specialised loops: fp32, 32-column path, no fused shortcut; register-staged three-slice stages or DMA-staged single slices");
   static_assert(!(DMA & 2) || !PRO, "the input tile can only be staged by DMA when no prologue transforms it on the way into LDS");
   constexpr bool BF16 = G::BF16;                // 16-bit storage, bf16 or half (ST says which)
   constexpr int ST = PREC;
@@ -352,8 +328,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
   float* sA = smem;
   float* sB = smem + G::NA * G::SA;
 
-  const int role = WS ? (int)(threadIdx.x >> 8) : 0;      // warp-specialised: 1 = loader wave
-  const int tid = WS ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+  const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int kw = KW == 1 ? 0 : (tid >> 8);      // wave group (in-workgroup K slice)
   const int wave = (tid >> 6) & 3;
@@ -383,13 +358,6 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
   for (int mf = 0; mf < MF; ++mf) fy[mf] = (wm * MF + mf) * G::FRH + li / FRW;
 
   f32x16 acc[PH * MF][NFE];   // UPS: accumulator set ph*MF + mf belongs to phase ph = py*2 + px
-  // experiment (RIB_EXP bit 2): two interleaved accumulation chains for single-fragment waves
-  constexpr bool DUAL = (RIB_EXP & 4) && PREC == PREC_F32 && !N16 && !UPS && MF * NFE == 1;
-  f32x16 accb;
-  if (DUAL) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-  }
   f32x4 acc16[MF][2];     // 16-column path: two 16-pixel sub-fragments (tile rows) per 32-pixel block
   if (!N16) {
 #pragma unroll
@@ -425,8 +393,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
       const int row = idx / GPRB, c4 = idx % GPRB;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < G::BN && n0 + row < p.CoutPad)
-        v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
-                          : *reinterpret_cast<const float4*>(wb + w_off(n0 + row, tap, kc, c4));
+        v = *reinterpret_cast<const float4*>(wb + w_off(n0 + row, tap, kc, c4));
       breg[i] = v;
     }
   };
@@ -449,8 +416,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
         const int row = idx / GPRB, c4 = idx % GPRB;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < G::BN && n0 + row < p.CoutPad)
-          v = (RIB_EXP & 1) ? *reinterpret_cast<const float4*>(p.w + (tid + i * NT) * 4)
-                            : *reinterpret_cast<const float4*>(wb + w_off(n0 + row, dy * (TB == 4 ? 4 : 3) + t, kc, c4));
+          v = *reinterpret_cast<const float4*>(wb + w_off(n0 + row, dy * (TB == 4 ? 4 : 3) + t, kc, c4));
         breg[(TB > 1 ? t : 0) * G::NB4 + i] = v;
       }
   };
@@ -661,12 +627,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
         if constexpr (DMA & 1) b[nf] = *reinterpret_cast<const float4*>(sBrow + nf * 32 * G::BP + G::swz(rb0 + nf * 32, kb * 2 + lh) * 4);
         else b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
       }
-      if constexpr (DUAL) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc[0][0], 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, accb, 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc[0][0], 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, accb, 0, 0, 0);
-      } else {
+      {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -783,109 +744,28 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
       if (more) { sA = smem + (buf ^ 1) * G::SA; writeA(false); storeB3(buf ^ 1); }
     }
     sA = smem;
-  } else if constexpr (TB == 3 && WS) {
-    // ---- warp-specialised: a stage = the three filter slices of one filter row (and, at row 0, the chunk's input tile, double-
-    // buffered).  Loader waves 4-7 run one stage ahead: while the consumer waves 0-3 issue the MFMAs of stage s they commit
-    // stage s + 1 to LDS (filters loaded during stage s - 1, tile prefetched a chunk ahead) and issue the loads of stage s + 2;
-    // ONE barrier per stage for everybody.  The consumers' instruction stream is fragment reads and MFMAs only (the stamps of
-    // tools/probes/igemm_harness.hip: a quarter to a third of a wave's time was staging in the unspecialised loop).
-    const int nst = ((kc_end - kc_begin) / BK) * 3;
-    consumer_stats();
-    if (role) {
-      loadB3(kc_begin, 0);
-      prefetchA(kc_begin);
-      writeA(false);
-      storeB3(0);
-      if (nst > 1) loadB3(kc_begin, 1);
-      if (kc_begin + BK < kc_end) prefetchA(kc_begin + BK);
-      __syncthreads();                                   // stage 0 is in LDS
-      int kc = kc_begin, dy = 0;
-#pragma unroll 1
-      for (int s = 0; s < nst; ++s) {
-        int ndy = dy + 1, nkc = kc;
-        if (ndy == 3) { ndy = 0; nkc = kc + BK; }
-        RIB_TS(ta);
-        if (s + 1 < nst) {
-          storeB3((s + 1) & 1);                          // (the consumers left this buffer at the barrier of stage s)
-          RIB_TS(tb); RIB_TACC(0, ta, tb);
-          if (ndy == 0 && !(RIB_EXP & 2)) {
-            sA = smem + (((nkc - kc_begin) / BK) & 1) * G::SA;
-            writeA(false);
-            if (nkc + BK < kc_end) prefetchA(nkc + BK);
-          }
-          RIB_TS(tc); RIB_TACC(1, tb, tc);
-          int n2dy = ndy + 1, n2kc = nkc;
-          if (n2dy == 3) { n2dy = 0; n2kc = nkc + BK; }
-          if (s + 2 < nst) loadB3(n2kc, n2dy);
-          RIB_TS(td); RIB_TACC(3, tc, td);
-        }
-        RIB_TS(te);
-        __syncthreads();                                 // stage s + 1 is in LDS; the consumers are done with stage s
-        RIB_TS(tf); RIB_TACC(2, te, tf);
-        dy = ndy; kc = nkc;
-      }
-#if RIB_EXP & 2048
-      if ((threadIdx.x & 63) == 0) {      // loader waves: 0 filter store (incl. the wait for its loads), 1 tile commit + prefetch, 2 barrier wait, 3 load issue
-        const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-        long long* d = g_igemm_stamps + (((size_t)gridDim.x * gridDim.y * gridDim.z + wg) * 4 + ((threadIdx.x >> 6) & 3)) * 8;
-        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tacc[3]; d[4] = clock64() - t_begin; d[5] = t_begin;
-      }
-#endif
-      return;
-    }
-    {
-      RIB_TS(tp0);
-      __syncthreads();
-      RIB_TS(tp1); RIB_TACC(0, tp0, tp1);      // (stamps: 0 = the consumers' wait for stage 0; 1 = kernel start to here)
-#if RIB_EXP & 2048
-      tacc[1] = tp1 - t_begin;
-#endif
-    }
-    {
-      int c = 0, dy = 0;
-#pragma unroll 1
-      for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        sA = smem + (c & 1) * G::SA;
-        RIB_TS(ta);
-        compute_tap(dy, 0, buf * 3 + 0);
-        compute_tap(dy, 1, buf * 3 + 1);
-        compute_tap(dy, 2, buf * 3 + 2);
-        RIB_TS(tb); RIB_TACC(3, ta, tb);
-        __syncthreads();
-        RIB_TS(tc); RIB_TACC(2, tb, tc);
-        if (++dy == 3) { dy = 0; ++c; }
-      }
-    }
-    sA = smem;
   } else if constexpr (TB == 3) {
     loadB3(kc_begin, 0);
     prefetchA(kc_begin);
     consumer_stats();
     int stage = 0;
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
-      RIB_TS(t0);
       __syncthreads();
-      if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
-      RIB_TS(t1); RIB_TACC(0, t0, t1);
+      writeA(false);
 #pragma unroll 1
       for (int dy = 0; dy < 3; ++dy, ++stage) {
         const int buf = stage & 1;
-        RIB_TS(ta);
         storeB3(buf);
         {
           int ndy = dy + 1, nkc = kc;
           if (ndy == 3) { ndy = 0; nkc = kc + BK; }
           if (nkc < kc_end) loadB3(nkc, ndy);
         }
-        if (!(RIB_EXP & 2) && dy == 0 && kc + BK < kc_end) prefetchA(kc + BK);
-        RIB_TS(tb); RIB_TACC(1, ta, tb);
+        if (dy == 0 && kc + BK < kc_end) prefetchA(kc + BK);
         __syncthreads();
-        RIB_TS(tc); RIB_TACC(2, tb, tc);
         compute_tap(dy, 0, buf * 3 + 0);
         compute_tap(dy, 1, buf * 3 + 1);
         compute_tap(dy, 2, buf * 3 + 2);
-        RIB_TS(td); RIB_TACC(3, tc, td);
       }
     }
   } else if constexpr (DM != 0) {
@@ -907,6 +787,9 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
       const int row = L / S, ls = G::swz(row, L % S);
       bsrc[q] = wb + ((size_t)min(n0 + min(row, G::BN - 1), p.CoutPad - 1) * wrow + ls * 4) * 4;
     }
+    // (m0 cannot be named in the clobber list: the AMDGPU backend treats it as a reserved register and rejects the clobber with
+    // -Winline-asm "may not be preserved".  It writes m0 itself immediately in front of each of ITS m0 consumers - movrel, LDS-DMA
+    // builtins, s_sendmsg - and these kernels contain none of those, so nothing of the compiler's is live in m0 across the asm.)
     auto fillB = [&](int buf, int kc, int tap) {
 #pragma unroll
       for (int q = 0; q < G::NQB; ++q) {
@@ -969,39 +852,6 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
         st ^= 1;
       }
       sA = smem;
-    } else if constexpr (WS) {
-      // ---- warp-specialised (DMA-staged tile and filters): the loader waves issue every fill - a DMA instruction takes ~250
-      // cycles to issue while the memory pipeline is busy (stamps), time the consumer waves now spend on MFMAs - wait for their own
-      // part to land and meet the consumers at the slice's barrier; same two-buffer protocol as below
-      const int nsl = ((kc_end - kc_begin) / BK) * G::TAPS;
-      if (role) {
-        fillA(0, kc_begin);
-        fillB(0, kc_begin, 0);
-        int kc = kc_begin, tap = 0, abuf = 0;
-#pragma unroll 1
-        for (int s = 0; s < nsl; ++s) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();                                 // slice s has landed; the consumers are done with slice s - 1
-          int ntap = tap + 1, nkc = kc;
-          if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
-          if (nkc < kc_end) fillB((s & 1) ^ 1, nkc, ntap);
-          if (tap == 0 && kc + BK < kc_end) fillA(abuf ^ 1, kc + BK);
-          if (ntap == 0) abuf ^= 1;
-          tap = ntap; kc = nkc;
-        }
-        return;
-      }
-      {
-        int tap = 0, abuf = 0;
-#pragma unroll 1
-        for (int s = 0; s < nsl; ++s) {
-          __syncthreads();
-          sA = smem + abuf * G::SA;
-          compute_tap(tap / KS, tap % KS, s & 1);
-          if (++tap == G::TAPS) { tap = 0; abuf ^= 1; }
-        }
-      }
-      sA = smem;
     } else {
     if constexpr (DMA & 2) fillA(0, kc_begin); else prefetchA(kc_begin);
     fillB(0, kc_begin, 0);
@@ -1014,11 +864,8 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
 #pragma unroll 1
       for (int tap = 0; tap < G::TAPS; ++tap, ++stage) {
         const int buf = stage & 1;
-        RIB_TS(ta);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slice `tap` (and, at slice 0, of the chunk's input tile) has landed
-        RIB_TS(tb); RIB_TACC(0, ta, tb);                     // (stamps: 0 = waiting for the own fills here)
         __syncthreads();                                      // ... and everybody's; everybody is done with slice tap - 1
-        RIB_TS(tc); RIB_TACC(2, tb, tc);
         {
           int ntap = tap + 1, nkc = kc;
           if (ntap == G::TAPS) { ntap = 0; nkc = kc + BK; }
@@ -1027,74 +874,23 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
         if (tap == 0 && kc + BK < kc_end) {
           if constexpr (DMA & 2) fillA(abuf ^ 1, kc + BK); else prefetchA(kc + BK);
         }
-        RIB_TS(td); RIB_TACC(1, tc, td);
         if constexpr (DMA & 2) sA = smem + abuf * G::SA;
         compute_tap(tap / KS, tap % KS, buf);
-        RIB_TS(te); RIB_TACC(3, td, te);
       }
       abuf ^= 1;
     }
     sA = smem;
-    }
-  } else if constexpr ((RIB_EXP & 32) && KS == 1 && STRIDE == 1 && !UPS && PREC == PREC_F32 && TB == 1 && KW == 1 && !N16) {
-    // EXPERIMENT (tools/probes/spade_harness.hip, -DRIB_EXP=32): 1x1 convolutions have no halo, so with WN == 1 every
-    // input pixel is used by exactly one wave and staging it through LDS buys no reuse: read the A fragments straight
-    // from global memory in MFMA operand layout (lane = pixel li, channels kb*8 + lh*4 .. +3), double-buffered in
-    // registers; only the filters go through LDS (one barrier per chunk)
-    size_t pixoff[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-      pixoff[mf] = (size_t)(min(ty0 + fy[mf], p.Hin - 1) * p.Win + min(tx0 + fx, p.Win - 1)) * p.xC * 4;
-    float4 afr[2][MF][BK / 8];
-    auto loadAf = [&](int kc, int b) {
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb)
-          afr[b][mf][kb] = *reinterpret_cast<const float4*>(xn + pixoff[mf] + (size_t)(kc + kb * 8 + lh * 4) * 4);
-    };
-    loadB(kc_begin, 0);
-    loadAf(kc_begin, 0);
-    consumer_stats();
-    int st = 0;
-#pragma unroll 2
-    for (int kc = kc_begin; kc < kc_end; kc += BK, ++st) {
-      const int buf = st & 1;
-      storeB(buf);
-      if (kc + BK < kc_end) { loadB(kc + BK, 0); loadAf(kc + BK, buf ^ 1); }
-      __syncthreads();
-      const float* sBrow = sB + buf * G::SB + (wn * NFE * 32 + li) * G::CK;
-#pragma unroll
-      for (int kb = 0; kb < BK / 8; ++kb) {
-        float4 b[NFE];
-#pragma unroll
-        for (int nf = 0; nf < NFE; ++nf) b[nf] = *reinterpret_cast<const float4*>(sBrow + lh * 4 + nf * 32 * G::CK + kb * 8);
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-          for (int nf = 0; nf < NFE; ++nf) {
-            const float4 a = afr[buf][mf][kb];
-            f32x16& d = acc[mf][nf];
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nf].x, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nf].y, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nf].z, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nf].w, d, 0, 0, 0);
-          }
-      }
     }
   } else {
   loadB(kc_begin, 0);
   prefetchA(kc_begin);
   consumer_stats();
   for (int kc = kc_begin; kc < kc_end; kc += BK) {
-    RIB_TS(t0);
     __syncthreads();   // every wave is done reading sA / sB of the previous chunk
-    if (!(RIB_EXP & 2) || kc == kc_begin) writeA(false);
-    RIB_TS(t1); RIB_TACC(0, t0, t1);
+    writeA(false);
 #pragma unroll 1
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int buf = tap & 1;
-      RIB_TS(ta);
       storeB(buf);
       {  // prefetch the next filter slice while this tap computes
         int ntap = tap + 1, nkc = kc;
@@ -1103,23 +899,13 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
       }
       // next input chunk: issued AFTER the filter load so that the in-order vmcnt wait at the
       // next storeB does not have to cover it
-      if (!(RIB_EXP & 2) && tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
-      RIB_TS(tb); RIB_TACC(1, ta, tb);
+      if (tap == 0 && kc + BK < kc_end) prefetchA(kc + BK);
       __syncthreads();
-      RIB_TS(tc); RIB_TACC(2, tb, tc);
       compute_tap(tap / KS, tap % KS, buf);
-      RIB_TS(td); RIB_TACC(3, tc, td);
     }
   }
   }
 
-#if RIB_EXP & 2048
-  if ((threadIdx.x & 63) == 0) {
-    const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-    long long* d = g_igemm_stamps + (wg * (256 * KW / 64) + (threadIdx.x >> 6)) * 8;
-    d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tacc[3]; d[4] = clock64() - t_begin; d[5] = t_begin;
-  }
-#endif
   // ---- fused 1x1 operand (learned shortcut): extra K chunks on the centre tap, last K slice only ----
   if constexpr (AUX && KS == 3 && STRIDE == 1 && !UPS && !SPADE) if (p.x2 != nullptr && split == p.ksplit - 1) {
     const char* x2n = reinterpret_cast<const char*>(p.x2) + (size_t)n * p.Hin * p.Win * p.x2C * ESZ;
@@ -1157,11 +943,6 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
       __syncthreads();
       compute_tap(1, 1, 0);
     }
-  }
-
-  if constexpr (DUAL) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] += accb[r];
   }
 
   if constexpr (KW > 1) {
@@ -1549,7 +1330,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int RY = (8 * (r >> 2)) / FRW, RX = (8 * (r >> 2)) % FRW + (r & 3);
-            xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<ST>(p.xm, xbase + (size_t)(RY >> s) * xrow + (size_t)(RX >> s) * p.xmC);
+            xr[r] = ld_act<ST>(p.xm, xbase + (size_t)(RY >> s) * xrow + (size_t)(RX >> s) * p.xmC);
           }
           if (vvalid) {
             const size_t yrow = (size_t)p.Wout * p.C;
@@ -1561,7 +1342,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
               const float beta = acc[mf][2 * q + 1][r] + bb;
               float o = (xr[r] * sc + sh) * (1.f + gamma) + beta;
               o = apply_act(o, act);
-              if (!(RIB_EXP & 16) || o == 123.456f) st_act<ST>(yout, ybase + (size_t)RY * yrow + (size_t)RX * p.C, o);
+              st_act<ST>(yout, ybase + (size_t)RY * yrow + (size_t)RX * p.C, o);
             }
           }
         } else {
@@ -1571,7 +1352,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
           const int oy = min(ty0 + (wm * MF + mf) * G::FRH + row / FRW, p.Hout - 1);
           const int ox = min(tx0 + row % FRW, p.Wout - 1);
           const int sy = p.xm_ups ? (oy >> 1) : oy, sx = p.xm_ups ? (ox >> 1) : ox;
-          xr[r] = (RIB_EXP & 8) ? 1.f : ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
+          xr[r] = ld_act<ST>(p.xm, (((size_t)n * Hm + sy) * Wm + sx) * p.xmC + (vvalid ? c : 0));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1584,7 +1365,7 @@ __global__ __launch_bounds__(256 * KW * ((DMA & 4) ? 2 : 1), (DMA & 4) ? 1 : ((P
             const float beta = acc[mf][2 * q + 1][r] + bb;
             float o = (xv * sc + sh) * (1.f + gamma) + beta;
             o = apply_act(o, act);
-            if (!(RIB_EXP & 16) || o == 123.456f) st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
+            st_act<ST>(yout, (((size_t)n * p.Hout + oy) * p.Wout + ox) * p.C + c, o);
           }
         }
         }
@@ -2857,12 +2638,6 @@ struct LowcParams {
   int tilesX, tilesY;
 };
 
-#if RIB_EXP & 1024
-__device__ long long* g_lowc_stamps;      // tools/probes/lowc_harness.hip: [workgroup][8] s_memtime stamps of the phases
-#define RIB_STAMP(i) do { if (threadIdx.x == 0) g_lowc_stamps[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
-#else
-#define RIB_STAMP(i) do { } while (0)
-#endif
 template <int CE, int NCOL, int ST, int TW = 32>
 __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   constexpr bool N16 = NCOL == 16;
@@ -2883,7 +2658,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   const int ty0 = (tile / p.tilesX) * TH, tx0 = (tile % p.tilesX) * TW;
   const int ctot = p.c0 + p.c1 + p.c2;
   const size_t HW = (size_t)p.H * p.W;
-  RIB_STAMP(0);
   // ---- stage the halo tile: all of a thread's loads are issued before the first LDS store (one memory round trip) ----
   {
     constexpr int TOT = CE * IH * IW, NIT = (TOT + 255) / 256;
@@ -2895,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       const int y = rem / IW, x = rem - y * IW;
       const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
       v[it] = 0.f;
-      if (!(RIB_EXP & 256) && i < TOT && c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+      if (i < TOT && c < ctot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
         const float* src; int cc, cn;
         if (c < p.c0) { src = p.s0; cc = c; cn = p.c0; }
         else if (c < p.c0 + p.c1) { src = p.s1; cc = c - p.c0; cn = p.c1; }
@@ -2911,7 +2685,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       if (i < TOT) sA[(y * IW + x) * CP + c] = v[it];
     }
   }
-  RIB_STAMP(1);
   // ---- this lane's filter fragments (registers; after the staging so that its 30 values in flight are dead: 116 instead
   // of 198 VGPRs on the 22-channel layers) ----
   // More than 64 of them (the 22-channel layers: 99) are loaded in two halves: 99 + 32 accumulators is 3 waves per SIMD,
@@ -2929,7 +2702,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
   };
   load_b(0);
   __syncthreads();
-  RIB_STAMP(2);
   double s1 = 0.0, s2 = 0.0;                      // this lane's column: sum and sum of squares over its valid pixels
   if constexpr (!N16) {
     const int li = lane & 31, lh = lane >> 5;
@@ -2956,17 +2728,12 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
             const float a = pa[off + mf * IW * CP];
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
-              if (RIB_EXP & 64) acc[mf][nf][0] += a * bw[sl][nf];      // (tools/probes/lowc_harness.hip: the kernel without its MFMAs)
-              else acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[sl][nf], acc[mf][nf], 0, 0, 0);
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[sl][nf], acc[mf][nf], 0, 0, 0);
             }
           }
         }
       }
     }
-#if RIB_EXP & 1024
-    if (acc[0][0][0] == 123.456f) g_lowc_stamps[1 << 20] = 1;      // (the stamp waits for the accumulators)
-#endif
-    RIB_STAMP(3);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int col = nf * 32 + li;
@@ -2983,9 +2750,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
           float v = apply_act(acc[mf][nf][r] + bv, p.act);
           if (ST != ST_F32) v = round16<ST>(v);
           const bool ok = cok && oy < p.H && ox < p.W;
-          if (ok && (!(RIB_EXP & 128) || v == 123.456f)) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+          if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
           v = ok ? v : 0.f;
-          if (!(RIB_EXP & 512)) { c1 += (double)v; c2 += (double)v * (double)v; }
+          c1 += (double)v; c2 += (double)v * (double)v;
         }
       }
       if (p.stat_part) {
@@ -3009,8 +2776,7 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
 #pragma unroll
       for (int f = 0; f < NFR; ++f) {
         const float a = pa[off + (TW == 32 ? ((f >> 1) * IW + (f & 1) * 16) : f * IW) * CP];
-        if (RIB_EXP & 64) acc[f][0] += a * bw[s][0];
-        else acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][0], acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s][0], acc[f], 0, 0, 0);
       }
     }
     const int col = l15;
@@ -3025,9 +2791,9 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
         float v = apply_act(acc[f][r] + bv, p.act);
         if (ST != ST_F32) v = round16<ST>(v);
         const bool ok = cok && oy < p.H && ox < p.W;
-        if (ok && (!(RIB_EXP & 128) || v == 123.456f)) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
+        if (ok) st_act<ST>(p.y, ((size_t)n * HW + (size_t)oy * p.W + ox) * p.yC + p.yoff + col, v);
         v = ok ? v : 0.f;
-        if (!(RIB_EXP & 512)) { s1 += (double)v; s2 += (double)v * (double)v; }
+        s1 += (double)v; s2 += (double)v * (double)v;
       }
     }
     if (p.stat_part) {
@@ -3036,7 +2802,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       if (lq == 0) { red[wave][col][0] = s1; red[wave][col][1] = s2; }
     }
   }
-  RIB_STAMP(4);
   if (p.stat_part) {
     __syncthreads();
     for (int c = tid; c < p.CoutPad; c += 256) {
@@ -3052,7 +2817,6 @@ __global__ __launch_bounds__(256) void k_conv_lowc(const LowcParams p) {
       }
     }
   }
-  RIB_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -551,6 +551,14 @@ void ribm_destroy(ribm_handle* h) {
 
 const char* ribm_last_error(const ribm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+#ifndef RIB_BUILD_STAMP
+#error "compile through csrc/build.py (-DRIB_BUILD_STAMP: content hash of the sources, see build.py)"
+#endif
+const char* ribm_build_info(void) {
+  static const char stamp[] = "rib-stamp motion " RIB_BUILD_STAMP;      // (build.py looks for this string in the library)
+  return stamp;
+}
+
 int ribm_num_tensors(const ribm_handle* h) { return h ? (int)h->tensors.size() : 0; }
 
 int ribm_tensor_info(const ribm_handle* h, int idx, const char** name, int* ndim, int64_t dims[2]) {

@@ -14,6 +14,7 @@
 #include "../../include/rib.h"
 
 #include <algorithm>
+#include <array>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -61,6 +62,16 @@
 #undef RIB_VD9
 
 using namespace rib;
+
+#if !defined(RIB_BUILD_STAMP) || !defined(RIB_SHARD_STAMP)
+#error "compile through csrc/build.py (-DRIB_BUILD_STAMP / -DRIB_SHARD_STAMP: content hashes of the sources, see build.py)"
+#endif
+// the stamp strings of the eight k_igemm shard objects (igemm_shard.hip) and this object's own
+extern "C" {
+extern const char rib_stamp_section_0[], rib_stamp_section_1[], rib_stamp_section_2[], rib_stamp_section_3[],
+    rib_stamp_section_4[], rib_stamp_section_5[], rib_stamp_section_6[], rib_stamp_section_7[];
+}
+extern "C" __attribute__((used, visibility("hidden"))) const char kLibStamp[] = "rib-stamp lib " RIB_BUILD_STAMP;
 
 namespace {
 
@@ -593,7 +604,7 @@ struct rib_handle {
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
   int esz() const { return mc16() ? 2 : 4; }                       // bytes per stored activation element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
-  std::map<uint64_t, std::unique_ptr<Plan>> plans;
+  std::map<std::array<int, 5>, std::unique_ptr<Plan>> plans;      // key {flags, tuneB, B, H, W}: see get_plan
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
   // profiling
@@ -667,7 +678,8 @@ int fill_wino_set(rib_handle* h, int si, hipStream_t st) {
 }
 
 // index of the F(wm x wm) filter set of conv `ci`, created on first use (plan build): device memory + the transform when the
-// weights are already there.  Synchronises the device once per new set (plan builds are one-time work).  < 0: error (h->err).
+// weights are already there.  Synchronises the device (before and after the transform) once per new set: plan builds are
+// one-time work, and include/rib.h says so for every entry point that can build a plan.  < 0: error (h->err).
 int ensure_wino_set(rib_handle* h, int ci, int wm) {
   auto it = h->wino_index.find({ci, wm});
   if (it != h->wino_index.end()) return it->second;
@@ -682,6 +694,9 @@ int ensure_wino_set(rib_handle* h, int ci, int wm) {
   h->wino_sets.push_back(ws);
   h->wino_index[{ci, wm}] = si;
   if (h->device >= 0 && h->weights_ready) {
+    // the blob may still be landing on a (non-blocking) stream of the caller's - rib_import_weights returns behind an
+    // asynchronous copy - and the NULL stream does not order against such a stream: drain the device first, then transform
+    if (hipDeviceSynchronize() != hipSuccess) { h->err = "Winograd filter transform: device not idle-able"; return -1; }
     if (fill_wino_set(h, si, nullptr) != RIB_OK) return -1;
     if (hipDeviceSynchronize() != hipSuccess) { h->err = "Winograd filter transform failed"; return -1; }
   }
@@ -1980,7 +1995,7 @@ inline bool plan_pairs(int B, int flags) {
 Plan* get_plan(rib_handle* h, int B, int H, int W, int flags = 0, int tuneB = 0) {
   const bool labels_only = (flags & PLAN_LABELS) != 0;
   if (!labels_only && !plan_pairs(B, 0)) flags &= ~PLAN_UNPAIRED;      // one frame plan where nothing is paired anyway
-  const uint64_t key = ((uint64_t)(flags & 3) << 62) | ((uint64_t)(tuneB & 0x3f) << 56) | ((uint64_t)B << 40) | ((uint64_t)H << 20) | (uint64_t)W;
+  const std::array<int, 5> key = {flags & 3, tuneB, B, H, W};
   auto it = h->plans.find(key);
   if (it != h->plans.end()) return it->second.get();
   const int mult = 1 << std::max(h->g.c.num_down_img, h->g.c.mask_down);
@@ -2551,7 +2566,7 @@ static_assert(sizeof(rib_stroke) == sizeof(RasterStroke) && sizeof(rib_stroke) =
 
 namespace {
 struct RasterLayout { size_t strokes, colors, peaks, weights, canvas, total; };
-RasterLayout raster_layout(int T, int H, int W, int n_edges, int n_maps, int radius) {
+static RasterLayout raster_layout(int T, int H, int W, int n_edges, int n_maps, int radius) {
   RasterLayout L; size_t o = 0;
   L.strokes = o; o += align256((size_t)T * n_edges * sizeof(rib_stroke));
   L.colors = o;  o += align256((size_t)n_edges * sizeof(uint32_t));
@@ -2621,7 +2636,7 @@ int rib_rasterise(rib_handle* h, int T, int H, int W, const rib_stroke* strokes,
 
 namespace {
 // label-only work is batched over the chain when it has more than one frame, on one stream (RIB_NO_LABEL_BATCH=1 disables)
-bool chain_batches_labels(const rib_handle* h, int T, int B) {
+static bool chain_batches_labels(const rib_handle* h, int T, int B) {
   // T * B * split-K (<= 16) indexes blockIdx.z (< 65536) of the batched launches
   return T > 1 && B < 128 && (long)T * B < 4096 && !getenv("RIB_NO_LABEL_BATCH");
 }
@@ -2815,6 +2830,24 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
 
 // ---- tuning hooks: enumerate kernel variants, pin a (variant, split-K) choice for one op of one
 // shape, and time a single op of the plan in isolation ----
+const char* rib_build_info(void) {
+  static const std::string info = [] {
+    const char* sh[8] = {rib_stamp_section_0, rib_stamp_section_1, rib_stamp_section_2, rib_stamp_section_3,
+                         rib_stamp_section_4, rib_stamp_section_5, rib_stamp_section_6, rib_stamp_section_7};
+    std::string s = std::string("librib stamp=") + (kLibStamp + sizeof("rib-stamp lib ") - 1) + " shards=";
+    bool ok = true;
+    for (int i = 0; i < 8; ++i) {
+      const char* hash = strrchr(sh[i], ' ');          // "rib-stamp shard<i> <hash>"
+      hash = hash ? hash + 1 : "?";
+      ok = ok && strcmp(hash, RIB_SHARD_STAMP) == 0;
+      s += std::string(i ? "," : "") + hash;
+    }
+    s += fmt(" consistent=%d variants=%d compiler=%s", ok ? 1 : 0, kNumVariants, __VERSION__);
+    return s;
+  }();
+  return info.c_str();
+}
+
 int rib_num_variants(void) { return kNumVariants; }
 
 int rib_variant_info(int idx, int geom[12]) {
@@ -2834,12 +2867,12 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
     h->choices[key] = {variant_idx, ksplit};
   }
   // the frame plans of this shape (paired and unpaired) are rebuilt on next use, and so are the labels-only plans of
-  // chains that follow this shape's choices (key: flags [63:62], tuneB [61:56], batch [55:40], H [39:20], W [19:0])
+  // chains that follow this shape's choices (key {flags, tuneB, batch, H, W})
   for (auto it = h->plans.begin(); it != h->plans.end();) {
-    const uint64_t k = it->first;
-    const bool labels = ((k >> 62) & PLAN_LABELS) != 0;
-    const bool same_hw = (int)((k >> 20) & 0xfffff) == H && (int)(k & 0xfffff) == W;
-    const bool follows = same_hw && (labels ? (int)((k >> 56) & 0x3f) == B : (int)((k >> 40) & 0xffff) == B);
+    const std::array<int, 5>& k = it->first;
+    const bool labels = (k[0] & PLAN_LABELS) != 0;
+    const bool same_hw = k[3] == H && k[4] == W;
+    const bool follows = same_hw && (labels ? k[1] == B : k[2] == B);
     if (follows) it = h->plans.erase(it); else ++it;
   }
   return RIB_OK;

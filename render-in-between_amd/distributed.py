@@ -6,6 +6,7 @@ the only collective is ONE broadcast of the folded weight blob at start-up.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import socket
 import subprocess
@@ -92,16 +93,37 @@ def init_process_group(backend: str = None, device: torch.device = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
-    # RCCL writes its debug output to STDOUT; with NCCL_DEBUG=VERSION (exported on the GPU boxes) that is a five-line banner at
-    # the first communicator, and NCCL_DEBUG_FILE does not move it.  stdout belongs to the callers' results (bench.py: ONE
-    # JSON line), so the banner level is lowered to warnings-only; any other level the user set stays, in a file of its own
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
-    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     kw = {}
     if backend == "nccl" and device is not None and torch.device(device).type == "cuda":
         kw["device_id"] = torch.device(device)
-    dist.init_process_group(backend=backend, **kw)
+    # RCCL (and gloo) print to STDOUT while a communicator comes up - with NCCL_DEBUG=VERSION, which is exported on the GPU
+    # boxes, a five-line banner - and stdout belongs to the callers' results (bench.py: ONE JSON line).  The environment is
+    # left as the user set it (NCCL_DEBUG, NCCL_DEBUG_FILE); instead file descriptor 1 points at stderr while the group
+    # and its first communicator are created (a one-element all-reduce forces the latter), and is restored afterwards.
+    with _stdout_to_stderr():
+        dist.init_process_group(backend=backend, **kw)
+        t = torch.zeros(1, dtype=torch.int32, device=kw.get("device_id", "cpu"))
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # C stdio buffers of the libraries that printed (a pipe is block-buffered)
+        except OSError:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def agree_or_raise(ok: bool, what: str, device=None):
@@ -134,8 +156,8 @@ def broadcast_blob(buf: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 def broadcast_weights(gen, src: int = 0) -> float:
     """Rank `src` holds loaded weights; every other rank receives the folded
-    device blob (one RCCL broadcast: ~0.3 GB in fp32 mode with the Winograd-domain filter sets of the deep layers,
-    ~0.19 GB bf16) and adopts it (rib_import_weights checks the blob's header: mode and layout must match).
+    device blob (one RCCL broadcast: 126 MB in fp32 mode - every handle makes the Winograd-domain filter sets it
+    needs on its own device - 188 MB in the 16-bit modes) and adopts it (rib_import_weights checks the blob's header: mode and layout must match).
     Returns the broadcast wall time in ms (synchronised)."""
     rank = dist.get_rank()
     if rank == src:

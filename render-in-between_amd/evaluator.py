@@ -13,8 +13,13 @@ Differences from the reference, none of which change a pixel:
   * the output quantisation runs on the GPU (rib_quantise);
   * the label maps of a whole segment are drawn on the GPU in one call (rib_rasterise) instead of
     per frame with scipy / numpy loops on the host (evaluator.py:221-229);
-  * file decode / encode runs on a thread pool, the quantised frames of a segment come back in
-    one pinned device-to-host copy, and the three phases are pipelined over segments (SURVEY 8 row
+  * independent segments of equal length are BATCHED: up to `batch` of them run as one chain of batch B
+    (rib_chain(T, B, ..): sample b of every step is segment b's frame), which is what fills the 256 CUs on
+    the 32x32 / 64x64 maps; a chain is cut into time chunks of `chunk` steps whose first `prev`
+    is the previous chunk's last fused frame on the device, so that decode, GPU work and PNG encode of
+    different chunks overlap (a unit of the pipeline is `chunk` x B frames);
+  * file decode / encode runs on a thread pool, the quantised frames of a chunk come back in
+    one pinned device-to-host copy, and the three phases are pipelined over chunks (SURVEY 8 row
     f-1: at hundreds of frames/s the per-frame .cpu() + PNG encode of evaluator.py:260-266 is the wall);
   * multi-GPU: the independent units (the segments between key frames, evaluator.py:240-244, over all clips,
     :169-171) are dealt round-robin to the ranks of the process group (distributed.shard_units); every rank
@@ -57,10 +62,16 @@ def _list(d, exts):
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=3, label_fn=None, png_compress_level=None, resize="cv2"):
-        """lanes: independent segments kept in flight on one GPU, each on its own HIP stream with
-        its own generator handle (measured on MI355X at 512x512: 284 -> 363 frames/s with 3 lanes;
-        the frames inside a segment stay strictly sequential).
+    def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=8, io_threads=None):
+        """batch: independent segments of equal length rendered as ONE chain of that batch size (None: by frame size,
+        `default_batch`; 1: every segment on its own, the round-1..3 behaviour).  Per-sample arithmetic does not depend
+        on the other samples of a batch, but a batch-B plan may pick other tile variants / split-K factors than the
+        batch-1 plan: frames agree with batch 1 to ~1e-5, not bit for bit.
+        chunk: time steps per rib_chain call (the pipeline's unit is chunk x B frames); 0 = whole segments.
+        lanes: independent chains kept in flight on one GPU, each on its own HIP stream with
+        its own generator handle (the frames inside a segment stay strictly sequential).
+        io_threads: decode / encode workers (None: the CPUs this process may run on, divided by the ranks of the job
+        sharing the host, at most 32).
         label_fn(frames, H, W) -> [T, 22, H, W]: rasteriser override for models that only speak the
         reference's call protocol (the tests pass the CPU oracle); by default the model's GPU
         rasteriser is used and a model without one is an error (no host fallback).
@@ -71,12 +82,19 @@ class Evaluator:
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
         self.label_fn = label_fn
-        self.png_compress_level = png_compress_level        # None: PIL's default, as the reference
+        # PNG compression: None = PIL's default (zlib level 6), which is what the reference's Image.save(name) writes
+        # (PGNR/utils/utils.py:139-142) - byte-identical files; a lower level trades file size for encode time
+        self.png_compress_level = png_compress_level
+        self.batch = None if batch is None else max(1, int(batch))
+        self.chunk = max(0, int(chunk))
         try:
             ncpu = len(os.sched_getaffinity(0))
         except AttributeError:
             ncpu = os.cpu_count() or 1
-        self.io_threads = max(1, min(16, ncpu))             # more decode / encode threads than cores only slow the launch thread
+        # N ranks on one host share its cores: LOCAL_WORLD_SIZE (torchrun) or WORLD_SIZE ranks each take their part, and one
+        # core per rank stays with the launch thread (5 k launches per 31-frame segment); more workers than cores only slow it
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+        self.io_threads = max(1, int(io_threads)) if io_threads else max(1, min(32, ncpu // ranks - 1))
         self._pool = None                                   # created on first use, kept across calls (thread start-up is ~2 ms each)
         self._finishers = None
         self.timings = {}                                   # seconds per phase of the last evaluate_from_folder
@@ -85,6 +103,28 @@ class Evaluator:
         self.gauss_sigma = getattr(cfg, "gauss_sigma", 5)
         self.skeleton_thres = getattr(cfg, "skeleton_thres", 0.001)
         self.foot_thres = getattr(cfg, "foot_thres", 0.001)
+
+    def default_batch(self):
+        """Segments per chain when the caller did not say: enough samples to fill 256 CUs on the deep (1/16-resolution,
+        512-channel) layers without growing the working set past the MALL - 8 at the reference's 320x480, 4 at 512x512
+        (measured: profiles/r04_driver.jsonl, r04_other_shapes.jsonl)."""
+        px = self.height * self.width
+        return 8 if px <= 320 * 480 else (4 if px <= 512 * 512 else (2 if px <= 1024 * 1024 else 1))
+
+    @staticmethod
+    def group_segments(segs, batch):
+        """[(key, frames)] -> [[segment index, ..]]: runs of up to `batch` segments of EQUAL length, in segment order
+        (a chain of batch B advances all its samples together, so they must have the same number of steps)."""
+        groups, open_by_len = [], {}
+        for si, (_, frames) in enumerate(segs):
+            g = open_by_len.get(len(frames))
+            if g is None:
+                g = open_by_len[len(frames)] = []
+                groups.append(g)
+            g.append(si)
+            if len(g) >= batch:
+                del open_by_len[len(frames)]
+        return groups
 
     def _lanes(self, model, nsegs):
         """(generator, stream) pairs for concurrent segments; None for single-lane / non-native models."""
@@ -175,7 +215,7 @@ class Evaluator:
         tm = self.timings = {"load": 0.0, "rasterise": 0.0, "generate": 0.0, "save": 0.0, "frames": 0}
         if self._pool is None:
             self._pool = ThreadPoolExecutor(self.io_threads)          # decode + encode workers
-            self._finishers = ThreadPoolExecutor(max(2, self.lanes))  # wait for a segment's copy, then fan out its encodes
+            self._finishers = ThreadPoolExecutor(max(4, self.lanes + 2))  # wait for a unit's copy, then fan out its encodes
         pool, finishers = self._pool, self._finishers
         native = hasattr(model, "chain") and hasattr(model, "quantise")
         gpu_labels = native and self.label_fn is None and hasattr(model, "rasterise")
@@ -224,19 +264,29 @@ class Evaluator:
                         my_segs.append(first_of[k])
                 unit += 1
             segs = [segs[si] for si in my_segs]
-            # native path: every segment gets one pinned staging buffer that the decode workers fill in place
-            # (no stack on the launch thread, and the upload from pinned memory is asynchronous)
-            stage, slot = {}, {}
+            # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of
+            # the pipeline with one pinned staging buffer that the decode workers fill in place (no stack on the launch
+            # thread, and the upload from pinned memory is asynchronous)
+            units, stage, slot = [], {}, {}
             if native:
-                for si, (k, frames) in enumerate(segs):
-                    stage[si] = torch.empty((len(frames), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
-                    for j, i in enumerate(frames):
-                        slot[i] = (si, j)
+                B_ = self.batch or self.default_batch()
+                for gi, members in enumerate(self.group_segments(segs, B_)):
+                    T = len(segs[members[0]][1])
+                    step = self.chunk if self.chunk > 0 else T
+                    for c0 in range(0, T, step):
+                        c1 = min(T, c0 + step)
+                        ui = len(units)
+                        units.append((gi, members, c0, c1))
+                        stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
+                        for b, si in enumerate(members):
+                            for t in range(c0, c1):
+                                slot[segs[si][1][t]] = (ui, t - c0, b)
 
             def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
                 dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
                 if i in slot:
-                    stage[slot[i][0]][slot[i][1]].copy_(dain)
+                    ui, t, b = slot[i]
+                    stage[ui][t, b].copy_(dain)
                     dain = None
                 # evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame
                 # of its segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale
@@ -247,74 +297,95 @@ class Evaluator:
                 if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
                     pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
                 return dain, gt, pose
-            need = sorted(set(my_keys) | {i for _, frames in segs for i in frames})
-            loads = {i: pool.submit(load, i) for i in need}                        # FIFO: earlier frames decode first
             keys = my_keys
-            lanes = self._lanes(model, len(segs)) if native else None
+            if native:
+                # decode in the order the launch thread will ask for the frames: unit by unit, the unit's key frames first
+                order, seen = [], set()
+                for gi, members, c0, c1 in units:
+                    want = [segs[si][0] for si in members] if c0 == 0 else []
+                    want += [segs[si][1][t] for t in range(c0, c1) for si in members]
+                    order += [i for i in want if not (i in seen or seen.add(i))]
+                order += [k for k in keys if k not in seen]
+            else:
+                order = sorted(set(my_keys) | {i for _, frames in segs for i in frames})
+            loads = {i: pool.submit(load, i) for i in order}                       # FIFO
+            ngroups = len({u[0] for u in units})
+            lanes = self._lanes(model, ngroups) if native else None
             futs = {}
             for k in keys:                                                         # key frames pass through (evaluator.py:240-244)
                 futs[k] = finishers.submit(lambda k=k, loads=loads, names=names: save_host(loads[k].result()[1].unsqueeze(0), names[k]))
-            for si, (k, frames) in enumerate(segs):
+            prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
+            for ui, (gi, members, c0, c1) in enumerate(units):
+                t0 = time.perf_counter()
+                Tc, Bc = c1 - c0, len(members)
+                got = [loads[segs[si][1][t]].result() for t in range(c0, c1) for si in members]      # (t, b) order
+                gt = torch.stack([loads[segs[si][0]].result()[1] for si in members]) if c0 == 0 else None
+                t1 = time.perf_counter()
+                tm["load"] += t1 - t0
+                poses = [g_[2] for g_ in got]
+                g, st = lanes[gi % len(lanes)] if lanes else (model, torch.cuda.current_stream(model.device))
+                # uploads (pageable host memory: synchronous with respect to their stream) and the label
+                # rasterisation go to a stream of their own, which is idle, so that they do not wait behind
+                # the previous unit of this lane; the lane joins through an event
+                if up is None:
+                    up = torch.cuda.Stream(device=model.device)
+                with torch.cuda.stream(up):
+                    if gpu_labels:
+                        lab = rasterise.rasterise_tables(g, poses, self.height, self.width, self.gauss_sigma)
+                    else:
+                        lab = self.make_labels(g if hasattr(g, "rasterise") else model, poses)
+                    lab = lab.to(g.device).reshape(Tc, Bc, *lab.shape[1:])            # [Tc,B,22,H,W]
+                    # ToTensor + Normalize(0.5, 0.5) of the uint8 frames on the GPU (HSM_auto_dataset.py:73-75)
+                    dn = stage[ui].to(g.device, non_blocking=True).permute(0, 1, 4, 2, 3).to(torch.float32)
+                    dn = ((dn / 255.0 - 0.5) / 0.5).contiguous()                      # [Tc,B,3,H,W]
+                    gtd = gt.to(g.device) if gt is not None else None
+                    ready = torch.cuda.Event()
+                    ready.record(up)
+                for t_ in (lab, dn, gtd):
+                    if t_ is not None:
+                        t_.record_stream(st)
+                with torch.cuda.stream(st):
+                    st.wait_event(ready)
+                    t2 = time.perf_counter()
+                    # evaluator.py:240-244,252: a segment starts from its key frame; inside it prev <- fused frame
+                    fz = g.chain(gtd if c0 == 0 else prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
+                    prev_of[gi] = fz[-1]
+                    q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
+                    pinned = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                    pinned.copy_(q, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                tm["rasterise"] += t2 - t1
+                tm["generate"] += time.perf_counter() - t2
+                out_frames = [segs[si][1][t] for t in range(c0, c1) for si in members]
+
+                def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd)):
+                    done.synchronize()
+                    qn = pinned.numpy()
+                    return list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
+                seg_fut = finishers.submit(finish)
+                for j, i in enumerate(out_frames):
+                    futs[i] = (seg_fut, j)
+            tm["units"] = tm.get("units", 0) + len(units)
+            for si, (k, frames) in enumerate([] if native else segs):             # any reference-protocol callable
                 t0 = time.perf_counter()
                 got = [loads[i].result() for i in frames]
                 gt = loads[k].result()[1].unsqueeze(0)
                 t1 = time.perf_counter()
                 tm["load"] += t1 - t0
                 poses = [g[2] for g in got]
-                dn = stage[si] if native else torch.stack([g[0] for g in got])
-                if native:
-                    g, st = lanes[si % len(lanes)] if lanes else (model, torch.cuda.current_stream(model.device))
-                    # uploads (pageable host memory: synchronous with respect to their stream) and the label
-                    # rasterisation go to a stream of their own, which is idle, so that they do not wait behind
-                    # the previous segment of this lane; the lane joins through an event
-                    if up is None:
-                        up = torch.cuda.Stream(device=model.device)
-                    with torch.cuda.stream(up):
-                        if gpu_labels:
-                            lab = rasterise.rasterise_tables(g, poses, self.height, self.width, self.gauss_sigma)
-                        else:
-                            lab = self.make_labels(g if hasattr(g, "rasterise") else model, poses)
-                        lab = lab.to(g.device).unsqueeze(1)                        # [T,1,22,H,W]
-                        # ToTensor + Normalize(0.5, 0.5) of the uint8 frames on the GPU (HSM_auto_dataset.py:73-75)
-                        dn = dn.to(g.device, non_blocking=True).permute(0, 3, 1, 2).to(torch.float32)
-                        dn = ((dn / 255.0 - 0.5) / 0.5).unsqueeze(1).contiguous()
-                        gtd = gt.to(g.device)
-                        ready = torch.cuda.Event()
-                        ready.record(up)
-                    for t_ in (lab, dn, gtd):
-                        t_.record_stream(st)
-                    with torch.cuda.stream(st):
-                        st.wait_event(ready)
-                        t2 = time.perf_counter()
-                        fz = g.chain(gtd, lab, dn, want_all=False)[2]
-                        q = g.quantise(fz.reshape(-1, *fz.shape[2:]))              # [T,H,W,3] uint8
-                        pinned = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
-                        pinned.copy_(q, non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(st)
-                    tm["rasterise"] += t2 - t1
-                    tm["generate"] += time.perf_counter() - t2
-
-                    def finish(done=done, pinned=pinned, frames=frames, names=names, keep=(fz, q, lab, dn, gtd)):
-                        done.synchronize()
-                        qn = pinned.numpy()
-                        return list(pool.map(lambda j: save_q(qn[j], names[frames[j]]), range(len(frames))))
-                    seg_fut = finishers.submit(finish)
-                    for j, i in enumerate(frames):
-                        futs[i] = (seg_fut, j)
-                else:                                                              # any reference-protocol callable
-                    dn = dn.unsqueeze(1)
-                    lab = self.make_labels(model, poses).unsqueeze(1)
-                    t2 = time.perf_counter()
-                    prev, outs = gt, []
-                    for t in range(len(frames)):
-                        img, mask = model(lab[t], None, dn[t], prev)
-                        prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
-                        outs.append(prev)
-                    tm["rasterise"] += t2 - t1
-                    tm["generate"] += time.perf_counter() - t2
-                    for t, i in enumerate(frames):
-                        futs[i] = pool.submit(save_host, outs[t], names[i])
+                dn = torch.stack([g[0] for g in got]).unsqueeze(1)
+                lab = self.make_labels(model, poses).unsqueeze(1)
+                t2 = time.perf_counter()
+                prev, outs = gt, []
+                for t in range(len(frames)):
+                    img, mask = model(lab[t], None, dn[t], prev)
+                    prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
+                    outs.append(prev)
+                tm["rasterise"] += t2 - t1
+                tm["generate"] += time.perf_counter() - t2
+                for t, i in enumerate(frames):
+                    futs[i] = pool.submit(save_host, outs[t], names[i])
             clip_outputs.append((names, futs))
             tm["frames"] += len(futs)
         t5 = time.perf_counter()

@@ -252,13 +252,12 @@ class Generator:
         ws = self._workspace(B, H, W)
         need = int(self._lib.rib_chain_workspace_bytes(self._h, T, B, H, W))      # + the batched label-only launches
         if need > ws.numel():
-            cws = self._chain_ws.get((T, B, H, W)) if hasattr(self, "_chain_ws") else None
-            if cws is None:
-                if not hasattr(self, "_chain_ws"):
-                    self._chain_ws = {}
-                self._chain_ws.clear()                                             # one chain shape at a time
-                cws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                self._chain_ws[(T, B, H, W)] = cws
+            # one grow-only buffer per batch size: the chunks of a segment differ in T (8, 8, 8, 7) and share it
+            cache = self.__dict__.setdefault("_chain_ws", {})
+            cws = cache.get((B, H, W))
+            if cws is None or cws.numel() < need:
+                cache.pop((B, H, W), None)
+                cws = cache[(B, H, W)] = torch.empty(need, dtype=torch.uint8, device=self.device)
             ws = cws
         fuses = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
         imgs = torch.empty_like(fuses) if want_all else None

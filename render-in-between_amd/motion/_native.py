@@ -28,6 +28,7 @@ SIGNATURES = {
     "ribm_create": (C.c_int, [C.POINTER(RibmConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "ribm_destroy": (None, [C.c_void_p]),
     "ribm_last_error": (C.c_char_p, [C.c_void_p]),
+    "ribm_build_info": (C.c_char_p, []),
     "ribm_num_tensors": (C.c_int, [C.c_void_p]),
     "ribm_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "ribm_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),

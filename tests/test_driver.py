@@ -259,3 +259,17 @@ def test_load_image_resizes_like_the_reference_transform(tmp_path):
     assert not torch.equal(t, tp)
     with pytest.raises(ValueError):
         ev.Evaluator(cfg, resize="area")
+
+
+def test_group_segments_batches_equal_lengths_only():
+    """Evaluator.group_segments: a chain of batch B advances all its samples together, so only segments with the same
+    number of frames share one; order is kept, a group closes at `batch` members, leftovers form smaller groups."""
+    segs = [(0, [1, 2, 3]), (4, [5, 6, 7]), (8, [9]), (10, [11, 12, 13]), (14, [15, 16, 17]), (18, [19, 20, 21])]
+    assert ev.Evaluator.group_segments(segs, 2) == [[0, 1], [2], [3, 4], [5]]
+    assert ev.Evaluator.group_segments(segs, 1) == [[0], [1], [2], [3], [4], [5]]
+    assert ev.Evaluator.group_segments(segs, 8) == [[0, 1, 3, 4, 5], [2]]
+    assert ev.Evaluator.group_segments([], 4) == []
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=320, model_width=480)
+    assert ev.Evaluator(cfg).default_batch() == 8
+    cfg.model_height = cfg.model_width = 512
+    assert ev.Evaluator(cfg).default_batch() == 4

@@ -54,6 +54,43 @@ def test_header_symbols_all_exported_and_bound(lib):
     assert fields == FIELDS
 
 
+def _build_module():
+    from importlib import util
+    spec = util.spec_from_file_location("rib_build", os.path.join(os.path.dirname(_native.LIB_PATH), "build.py"))
+    mod = util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_library_is_what_the_tracked_sources_build(lib):
+    """the measured binary must be the one the tree compiles to.  Every object of librib.so carries
+    the content hash of the sources it was compiled from (csrc/build.py); the hashes of the tree as it is now, the hashes
+    found in the .so file and the ones rib_build_info() reports at run time must all agree, for all nine objects."""
+    b = _build_module()
+    want = b.tree_stamps()
+    assert b.check() == [], "librib.so / libribmotion.so were not built from this tree: run csrc/build.py"
+    have = b.embedded_stamps(b.OUT)
+    assert {t: have.get(t) for t in want if t != "motion"} == {t: want[t] for t in want if t != "motion"}
+    info = _native.build_info()
+    assert info["consistent"] and info["stamp"] == want["lib"]
+    assert info["shards"] == [want["shard%d" % s] for s in range(b.NSECTIONS)]
+    assert info["variants"] == lib.rib_num_variants()
+    # a changed source changes the stamp (content, not mtime)
+    assert b.stamp_of(b.SHARD_DEPS, extra=("x",)) != want["shard0"]
+
+
+def test_library_exports_only_the_declared_c_abi(lib):
+    """No un-prefixed helper leaks out of librib.so: the defined dynamic function symbols are the
+    rib_* entry points of include/rib.h plus mangled C++ / HIP registration symbols."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    plain = [l.split()[-1] for l in out.splitlines() if l.split()[1] in "TtWw" and not l.split()[-1].startswith(("_Z", "__", "_init", "_fini"))]
+    stray = sorted(n for n in plain if not n.startswith("rib_"))
+    assert stray == [], stray
+    hdr = open(os.path.join(ROOT, "include", "rib.h")).read()
+    declared = set(re.findall(r"\b(rib_[a-z_]+)\s*\(", hdr))
+    assert set(plain) <= declared, sorted(set(plain) - declared)
+
+
 def test_native_inventory_matches_python_spec(lib):
     spec, h = host_handle(lib, rib.hsm_gen_config())
     want = dict(rib.state_dict_spec(spec))

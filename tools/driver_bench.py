@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rate of the folder driver (json + PNG in, PNG out) on a synthetic clip.
 
-    python tools/driver_bench.py [--size 512] [--keys 3] [--rate 32] [--lanes 3]
+    python tools/driver_bench.py [--size 512 | --height 320 --width 480] [--keys 5] [--rate 32] [--lanes 2] [--batch B] [--chunk 8]
 
 Writes a clip in the reference's directory layout (inputs/ DAIN/ Predict_motion/), runs
 Evaluator.evaluate_from_folder twice (the first run also builds launch plans) and prints the
@@ -47,28 +47,41 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--keys", type=int, default=3)
     ap.add_argument("--rate", type=int, default=32)
-    ap.add_argument("--lanes", type=int, default=3)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="segments per chain (0: the Evaluator's default for the frame size)")
+    ap.add_argument("--chunk", type=int, default=8)
+    ap.add_argument("--io-threads", type=int, default=0)
+    ap.add_argument("--compress", type=int, default=-1, help="PNG compress level (-1: PIL's default, 6, as the reference)")
+    ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
-    H = W = a.size
+    H, W = (a.height or a.size), (a.width or a.size)
     cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=H, model_width=W, gauss_sigma=5, skeleton_thres=0.001, foot_thres=0.001)
     spec = rib.GenSpec.from_cfg(cfg.gen)
     G = rib.Generator(cfg.gen, compute_dtype=a.dtype).eval()
     G.load_state_dict(synth.make_state_dict(spec, 0, power_iters=3))
     with tempfile.TemporaryDirectory() as root:
         n = write_clip(root, a.keys, a.rate, H, W)
-        E = ev.Evaluator(cfg, lanes=a.lanes)
+        E = ev.Evaluator(cfg, lanes=a.lanes, batch=a.batch or None, chunk=a.chunk, io_threads=a.io_threads or None,
+                         png_compress_level=None if a.compress < 0 else a.compress)
         dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
-        for rep in range(2):
+        walls = []
+        for rep in range(1 + a.reps):           # the first run also builds launch plans and pools: not counted
             t0 = time.perf_counter()
             out = E.evaluate_from_folder(G, *dirs, os.path.join(root, "out%d" % rep))
-            wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
         tm = dict(E.timings)
     gen = n - a.keys
-    print(json.dumps({"size": a.size, "dtype": a.dtype, "frames": n, "generated": gen, "lanes": a.lanes, "io_threads": E.io_threads,
-                      "wall_s": wall, "frames_per_s_end_to_end": n / wall,
-                      "phase_s": {k: round(v, 4) for k, v in tm.items() if k != "frames"},
-                      "generate_frames_per_s": gen / tm["generate"]}))
+    wall = sorted(walls[1:])[len(walls[1:]) // 2]
+    print(json.dumps({"height": H, "width": W, "dtype": a.dtype, "frames": n, "generated": gen, "lanes": a.lanes,
+                      "batch": a.batch or E.default_batch(), "chunk": a.chunk, "io_threads": E.io_threads,
+                      "cpus": len(os.sched_getaffinity(0)), "png_compress_level": a.compress,
+                      "wall_s": wall, "wall_s_runs": [round(w, 4) for w in walls[1:]], "frames_per_s_end_to_end": n / wall,
+                      "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units")},
+                      "pipeline_units_last_run": tm.get("units")}))
 
 
 if __name__ == "__main__":

@@ -47,7 +47,7 @@ def run(args):
     spec = rib.GenSpec.from_cfg(cfg)
     G = rib.Generator(cfg, compute_dtype=args.dtype).eval()
     G.load_state_dict(synth.make_state_dict(spec, 0))
-    label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, args.batch, args.size, args.size, 0)]
+    label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, args.batch, args.height or args.size, args.width or args.size, 0)]
     torch.cuda.synchronize()
     for _ in range(args.warmup + args.steps):
         G.forward_blend(label, None, fake, prev)           # bench.py's step: the mask head writes the fused frame
@@ -62,7 +62,7 @@ def report(args):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    ops = plan_names(args.batch, args.size, args.size, args.dtype)
+    ops = plan_names(args.batch, args.height or args.size, args.width or args.size, args.dtype)
     rows = [r for r in rows if r[2].startswith(("void rib::", "rib::"))]
     n = len(ops)
     total_steps = len(rows) // n
@@ -97,6 +97,8 @@ if __name__ == "__main__":
     ap.add_argument("--report", type=str, default=None)
     ap.add_argument("--json", type=str, default=None)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
