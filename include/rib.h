@@ -200,6 +200,11 @@ int rib_read_tap(rib_handle* h, int B, int H, int W, int idx, const void* worksp
 enum { RIB_KC_IGEMM = 0, RIB_KC_SPADE = 1, RIB_KC_STATS = 2, RIB_KC_POOL = 3, RIB_KC_ELTWISE = 4,
        RIB_KC_PACK = 5, RIB_KC_CONVAUX = 6, RIB_KC_COUNT = 7 };
 int rib_profile_begin(rib_handle* h);
+/* rib_profile_begin_kernels(): the same bookkeeping, but every launch carries a (start, stop) event pair bound to the
+ * dispatch itself (hipExtLaunchKernelGGL): rib_profile_collect() then returns the kernels' OWN execution times from the
+ * queue's timestamps - the durations rocprofv3 --kernel-trace reports, with no event packet between two launches; the
+ * classes no longer add up to the step (the dependent-launch gaps belong to no kernel). */
+int rib_profile_begin_kernels(rib_handle* h);
 int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms[RIB_KC_COUNT]);
 /* Algorithmic FLOPs (2*MAC) one rib_forward spends in class RIB_KC_IGEMM / RIB_KC_SPADE. */
 int rib_forward_flops(rib_handle* h, int B, int H, int W, double flops[RIB_KC_COUNT]);
@@ -215,6 +220,16 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
 int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const float* label,
                 const float* img_fake, const float* img_prev, float* img, float* mask, void* workspace,
                 size_t workspace_bytes, int iters, void* hip_stream, double* usec);
+
+/* ---- graph replay of rib_chain (no reference counterpart; a host-side option).  With it on (or RIB_GRAPH=1 in the
+ * environment at rib_create), the first rib_chain call with a given (T,B,H,W) AND a given set of pointers captures the
+ * segment's launches into one HIP graph and every later call with the same arguments is ONE hipGraphLaunch on the
+ * caller's stream; calls with other tensors capture their own graph (at most 8 are kept, least recently used first out).
+ * Same kernels, parameters and order: frames are bit-identical to the launch-by-launch path (tested).  Meant for hosts
+ * that drive many GPUs from few cores, where enqueueing ~130 launches per frame per GPU becomes the limiter.
+ * rib_graph_stats: how many calls captured / replayed since rib_create. ---- */
+int rib_set_graph_replay(rib_handle* h, int enable);
+int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays);
 
 /* ---- build identity (no reference counterpart: the reference is interpreted Python).  A static string
  *   "librib stamp=<lib> shards=<s0>,...,<s7> consistent=<0|1> variants=<n> compiler=<...>"

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rib_read_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     "rib_profile_begin": (C.c_int, [C.c_void_p]),
+    "rib_profile_begin_kernels": (C.c_int, [C.c_void_p]),
     "rib_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "rib_forward_flops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "rib_num_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "rib_debug_spade_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "rib_debug_launch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "rib_build_info": (C.c_char_p, []),
+    "rib_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
+    "rib_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 

@@ -11,6 +11,7 @@
 //   * the autoregressive segment driver (PGNR/models/evaluator.py:238-262).
 #include "kernels.hip.h"
 #include "raster.hip.h"
+#include <hip/hip_ext.h>
 #include "../../include/rib.h"
 
 #include <algorithm>
@@ -62,6 +63,17 @@
 #undef RIB_VD9
 
 using namespace rib;
+
+// Every kernel launch of this file goes through RIB_KLAUNCH.  Outside a kernel-time profiling pass it is hipLaunchKernelGGL; inside
+// one (rib_profile_begin_kernels) the launch carries a start and a stop event that the runtime binds to the dispatch itself
+// (hipExtLaunchKernelGGL): their difference is the kernel's own execution time from the queue's timestamps - what rocprofv3's
+// kernel trace reports - with no event packet between two launches.
+namespace { struct ProfPair { hipEvent_t start = nullptr, stop = nullptr; }; thread_local ProfPair g_prof_pair; }
+#define RIB_KLAUNCH(KERNEL, grid, block, lds, st, ...)                                                                       \
+  do {                                                                                                                       \
+    if (g_prof_pair.start) hipExtLaunchKernelGGL(KERNEL, grid, block, lds, st, g_prof_pair.start, g_prof_pair.stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, grid, block, lds, st, __VA_ARGS__);                                                      \
+  } while (0)
 
 #if !defined(RIB_BUILD_STAMP) || !defined(RIB_SHARD_STAMP)
 #error "compile through csrc/build.py (-DRIB_BUILD_STAMP / -DRIB_SHARD_STAMP: content hashes of the sources, see build.py)"
@@ -608,8 +620,17 @@ struct rib_handle {
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
   // profiling
+  // rib_chain graph replay (rib_set_graph_replay / RIB_GRAPH=1): instantiated graphs of whole segments, keyed by everything a
+  // launch parameter depends on - the shape and every pointer of the call; least recently used first out
+  struct ChainGraph { std::array<uintptr_t, 12> key; hipGraphExec_t exec; uint64_t used; };
+  std::vector<ChainGraph> chain_graphs;
+  bool graph_replay = false;
+  uint64_t graph_clock = 0, graph_captures = 0, graph_replays = 0;
   bool profiling = false;
+  bool prof_kernels = false;   // rib_profile_begin_kernels: (start, stop) pairs bound to the dispatches instead of interval events
   std::vector<std::pair<int, hipEvent_t>> prof_events;   // (class of the launch behind the event, -1: end of a plan run)
+  struct KernelEv { int kclass; hipEvent_t start, stop; };
+  std::vector<KernelEv> prof_kernel_events;
   int64_t prof_launches[RIB_KC_COUNT] = {0};
   double prof_ms[RIB_KC_COUNT] = {0};
 };
@@ -624,6 +645,12 @@ namespace {
       return RIB_ERR_HIP;                                                                  \
     }                                                                                      \
   } while (0)
+
+// instantiated chain graphs hold the plans' kernel parameters: whatever rebuilds plans or moves the blob drops them
+void drop_chain_graphs(rib_handle* h) {
+  for (auto& g : h->chain_graphs) (void)hipGraphExecDestroy(g.exec);
+  h->chain_graphs.clear();
+}
 
 int fail(rib_handle* h, int code, const std::string& msg) {
   h->err = msg;
@@ -672,7 +699,7 @@ int fill_wino_set(rib_handle* h, int si, hipStream_t st) {
   const ConvDef& c = h->convs[ws.conv];
   if (!ws.d || !h->d_blob) return RIB_OK;
   const size_t n = (size_t)c.coutp * c.cinp;
-  hipLaunchKernelGGL(k_wino_filters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d_blob + c.w_off, ws.d, c.coutp, c.cinp, ws.wm);
+  RIB_KLAUNCH(k_wino_filters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d_blob + c.w_off, ws.d, c.coutp, c.cinp, ws.wm);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -725,8 +752,8 @@ static bool lowc_instantiated(int ce, int ncol) {
 }
 // (fp32 storage only: the 16-bit modes pack their inputs and run the first layers on the 16-bit matrix cores)
 template <int CE, int NCOL> static void launch_lowc_t(int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
-  if (tw == 16) hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, ST_F32, 16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_lowc<CE, NCOL, ST_F32, 32>), grid, dim3(256), 0, st, p);
+  if (tw == 16) RIB_KLAUNCH((k_conv_lowc<CE, NCOL, ST_F32, 16>), grid, dim3(256), 0, st, p);
+  else RIB_KLAUNCH((k_conv_lowc<CE, NCOL, ST_F32, 32>), grid, dim3(256), 0, st, p);
 }
 static void launch_lowc(int ce, int ncol, int tw, dim3 grid, hipStream_t st, const LowcParams& p) {
   if (ce == 6 && ncol == 64) launch_lowc_t<6, 64>(tw, grid, st, p);
@@ -2040,20 +2067,20 @@ struct Resolver {
 // a kernel templated on the storage type alone, launched for the handle's precision mode
 #define RIB_LAUNCH_ST(prec, KERNEL, grid, block, lds, st, ...)                                                        \
   do {                                                                                                                \
-    if ((prec) == PREC_BF16) hipLaunchKernelGGL((KERNEL<ST_BF16>), grid, block, lds, st, __VA_ARGS__);                \
-    else if ((prec) == PREC_F16) hipLaunchKernelGGL((KERNEL<ST_F16>), grid, block, lds, st, __VA_ARGS__);             \
-    else hipLaunchKernelGGL((KERNEL<ST_F32>), grid, block, lds, st, __VA_ARGS__);                                     \
+    if ((prec) == PREC_BF16) RIB_KLAUNCH((KERNEL<ST_BF16>), grid, block, lds, st, __VA_ARGS__);                \
+    else if ((prec) == PREC_F16) RIB_KLAUNCH((KERNEL<ST_F16>), grid, block, lds, st, __VA_ARGS__);             \
+    else RIB_KLAUNCH((KERNEL<ST_F32>), grid, block, lds, st, __VA_ARGS__);                                     \
   } while (0)
 
 template <int CO, int CIN> void launch_head_t(int bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
-  if (bf16 == PREC_BF16) hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_BF16>), grid, dim3(256), 0, st, p);
-  else if (bf16 == PREC_F16) hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_F16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_conv_head<CO, CIN, ST_F32>), grid, dim3(256), 0, st, p);
+  if (bf16 == PREC_BF16) RIB_KLAUNCH((k_conv_head<CO, CIN, ST_BF16>), grid, dim3(256), 0, st, p);
+  else if (bf16 == PREC_F16) RIB_KLAUNCH((k_conv_head<CO, CIN, ST_F16>), grid, dim3(256), 0, st, p);
+  else RIB_KLAUNCH((k_conv_head<CO, CIN, ST_F32>), grid, dim3(256), 0, st, p);
 }
 template <int CO> void launch_small_t(int bf16, dim3 grid, size_t lds, hipStream_t st, const IgemmParams& p) {
-  if (bf16 == PREC_BF16) hipLaunchKernelGGL((k_conv_small<CO, ST_BF16>), grid, dim3(256), lds, st, p);
-  else if (bf16 == PREC_F16) hipLaunchKernelGGL((k_conv_small<CO, ST_F16>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((k_conv_small<CO, ST_F32>), grid, dim3(256), lds, st, p);
+  if (bf16 == PREC_BF16) RIB_KLAUNCH((k_conv_small<CO, ST_BF16>), grid, dim3(256), lds, st, p);
+  else if (bf16 == PREC_F16) RIB_KLAUNCH((k_conv_small<CO, ST_F16>), grid, dim3(256), lds, st, p);
+  else RIB_KLAUNCH((k_conv_small<CO, ST_F32>), grid, dim3(256), lds, st, p);
 }
 void launch_head(int co, int cin, int bf16, dim3 grid, hipStream_t st, const IgemmParams& p) {
   if (cin == 16) { if (co == 1) launch_head_t<1, 16>(bf16, grid, st, p); else if (co == 2) launch_head_t<2, 16>(bf16, grid, st, p); else launch_head_t<3, 16>(bf16, grid, st, p); }
@@ -2064,7 +2091,14 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
   const int bf16 = h->prec();       // storage type of the activations: PREC_F32 / PREC_BF16 / PREC_F16
   for (Op& op : P->ops) {
     if (skip_label_ops && op.label_only) continue;     // done for the whole chain by the labels-only plan
-    if (h->profiling) {      // one event in front of every launch (rib.h: a launch is charged the time to the next event)
+    g_prof_pair = ProfPair();
+    if (h->profiling && h->prof_kernels) {      // the launch below carries its own (start, stop) pair
+      ProfPair pp;
+      HIP_TRY(h, hipEventCreate(&pp.start));
+      HIP_TRY(h, hipEventCreate(&pp.stop));
+      h->prof_kernel_events.push_back({op.kclass, pp.start, pp.stop});
+      g_prof_pair = pp;
+    } else if (h->profiling) {      // one event in front of every launch (rib.h: a launch is charged the time to the next event)
       hipEvent_t e0 = nullptr;
       HIP_TRY(h, hipEventCreate(&e0));
       HIP_TRY(h, hipEventRecord(e0, st));
@@ -2097,19 +2131,19 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
             default: launch_small_t<4>(bf16, op.grid, lds, st, p); break;
           }
         } else
-        hipLaunchKernelGGL(pick_igemm_fn(op.var, p), op.grid, dim3(256 * op.var->KW), 0, st, p);
+        RIB_KLAUNCH(pick_igemm_fn(op.var, p), op.grid, dim3(256 * op.var->KW), 0, st, p);
       } break;
       case OP_GEMM: {
         GemmDmaParams p = op.gp;
         p.A = R.get<const float>(op.g_a); p.B = R.get<const float>(op.g_b); p.C = R.get<float>(op.g_c);
-        hipLaunchKernelGGL(op.var->gfn, op.grid, dim3(256), 0, st, p);
+        RIB_KLAUNCH(op.var->gfn, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_FINALIZE: {
         FinalizeParams p = op.fp;
         p.part = R.get<const double>(op.f_part); p.gamma = R.get<const float>(op.f_gamma); p.beta = R.get<const float>(op.f_beta);
         p.scale = R.get<float>(op.f_scale); p.shift = R.get<float>(op.f_shift);
-        if (p.tiles > 512) hipLaunchKernelGGL(k_stats_finalize<4>, dim3((p.Cs + 3) / 4, op.grid.y, op.grid.z), dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL(k_stats_finalize<16>, op.grid, dim3(1024), 0, st, p);
+        if (p.tiles > 512) RIB_KLAUNCH(k_stats_finalize<4>, dim3((p.Cs + 3) / 4, op.grid.y, op.grid.z), dim3(1024), 0, st, p);
+        else RIB_KLAUNCH(k_stats_finalize<16>, op.grid, dim3(1024), 0, st, p);
       } break;
       case OP_MODULATE: {
         ModulateParams p = op.mp;
@@ -2149,21 +2183,21 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
         p.pro2_scale = R.get<const float>(op.wi_sc2); p.pro2_shift = R.get<const float>(op.wi_sh2);
         p.st2.part = R.get<const double>(op.st_part[1]); p.st2.gamma = R.get<const float>(op.st_gamma[1]); p.st2.beta = R.get<const float>(op.st_beta[1]);
         if (op.wino_m == 4) {
-          if (op.wi_mode == WSRC_SPADE) hipLaunchKernelGGL(k_wino4_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
-          else if (op.wi_mode == WSRC_JOIN) hipLaunchKernelGGL(k_wino4_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
-          else hipLaunchKernelGGL(k_wino4_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
+          if (op.wi_mode == WSRC_SPADE) RIB_KLAUNCH(k_wino4_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
+          else if (op.wi_mode == WSRC_JOIN) RIB_KLAUNCH(k_wino4_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
+          else RIB_KLAUNCH(k_wino4_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
         } else {
-          if (op.wi_mode == WSRC_SPADE) hipLaunchKernelGGL(k_wino_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
-          else if (op.wi_mode == WSRC_JOIN) hipLaunchKernelGGL(k_wino_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
-          else hipLaunchKernelGGL(k_wino_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
+          if (op.wi_mode == WSRC_SPADE) RIB_KLAUNCH(k_wino_in<WSRC_SPADE>, op.grid, dim3(256), 0, st, p);
+          else if (op.wi_mode == WSRC_JOIN) RIB_KLAUNCH(k_wino_in<WSRC_JOIN>, op.grid, dim3(256), 0, st, p);
+          else RIB_KLAUNCH(k_wino_in<WSRC_PLAIN>, op.grid, dim3(256), 0, st, p);
         }
       } break;
       case OP_WINO_OUT: {
         WinoOutParams p = op.wo;
         p.m = R.get<const float>(op.wo_m); p.bias = R.get<const float>(op.wo_bias); p.y = R.get<float>(op.wo_y);
         p.res = R.get<const float>(op.wo_res); p.stat_part = R.get<double>(op.wo_stat);
-        if (op.wino_m == 4) hipLaunchKernelGGL(k_wino4_out, op.grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_wino_out, op.grid, dim3(256), 0, st, p);
+        if (op.wino_m == 4) RIB_KLAUNCH(k_wino4_out, op.grid, dim3(256), 0, st, p);
+        else RIB_KLAUNCH(k_wino_out, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_LOWC: {
         LowcParams p = op.lc;
@@ -2180,7 +2214,8 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
       } break;
     }
   }
-  if (h->profiling) {        // closes the last launch's interval
+  g_prof_pair = ProfPair();
+  if (h->profiling && !h->prof_kernels) {        // closes the last launch's interval
     hipEvent_t e1 = nullptr;
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e1, st));
@@ -2214,6 +2249,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
   if (c.emb_down != c.num_down_img) return bad("embed.num_downsamples must equal num_downsamples_img (HSM.yaml: 4/4)");
   std::unique_ptr<rib_handle> h(new rib_handle());
   h->g.c = c; h->device = device;
+  h->graph_replay = getenv("RIB_GRAPH") != nullptr && atoi(getenv("RIB_GRAPH")) != 0;
   for (int i = 0; i <= c.emb_down; ++i) {
     if (h->g.cond_ch(i) != h->g.emb_ch(i)) return bad("embed/generator max_num_filters disagree on the cond map width");
     if (h->g.emb_ch(i) % 32 != 0) return bad(fmt("embed width %d at level %d is not a multiple of 32", h->g.emb_ch(i), i));
@@ -2240,9 +2276,11 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 
 void rib_destroy(rib_handle* h) {
   if (!h) return;
+  drop_chain_graphs(h);
   if (h->d_blob) (void)hipFree(h->d_blob);
   free_wino_sets(h);
   for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
+  for (auto& ke : h->prof_kernel_events) { (void)hipEventDestroy(ke.start); (void)hipEventDestroy(ke.stop); }
   delete h;
 }
 
@@ -2409,6 +2447,7 @@ int rib_finalize_weights(rib_handle* h) {
   } else {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->d_blob_floats != h->blob_floats) {
+      drop_chain_graphs(h);
       if (h->d_blob) (void)hipFree(h->d_blob);
       h->d_blob = nullptr; h->d_blob_floats = 0;
       HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_blob), h->blob_floats * sizeof(float)));
@@ -2441,6 +2480,7 @@ int rib_import_weights(rib_handle* h, const void* src, size_t bytes, void* hip_s
   if (!src || bytes != h->blob_floats * sizeof(float)) return fail(h, RIB_ERR_INVALID, "rib_import_weights: size mismatch");
   if (h->device < 0) return fail(h, RIB_ERR_INVALID, "rib_import_weights: host-only handle");
   HIP_TRY(h, hipSetDevice(h->device));
+  drop_chain_graphs(h);      // (the blob may move)
   {   // the byte count alone does not identify a layout: check the header (a 32-byte read behind whatever filled src on this stream)
     BlobHeader got;
     HIP_TRY(h, hipMemcpyAsync(&got, src, sizeof got, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
@@ -2473,6 +2513,7 @@ int rib_set_compute_dtype(rib_handle* h, int dtype) {
   // rib_finalize_weights from the state-dict tensors the handle still holds, or by rib_import_weights from a blob
   // exported by a handle of the same storage type.
   h->plans.clear();
+  drop_chain_graphs(h);
   free_wino_sets(h);       // (plans reference them by index; the bf16 mode has none)
   h->choices.clear();      // tuned variant indices belong to the previous precision's kernels: back to the cost model until re-pinned
   h->prec_mode = mode;
@@ -2536,7 +2577,7 @@ int rib_blend(rib_handle* h, int B, int C, int H, int W, const float* img, const
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   const size_t total = (size_t)B * C * H * W;
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_blend, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, mask, dain, fuse, C, H * W, total);
+  RIB_KLAUNCH(k_blend, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, mask, dain, fuse, C, H * W, total);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -2546,7 +2587,7 @@ int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img, ui
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   const size_t total = (size_t)B * C * H * W;
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, out, C, H * W, total);
+  RIB_KLAUNCH(k_quantise, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), img, out, C, H * W, total);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -2557,7 +2598,7 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
   if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
   const int tilesX = (W + WARP_T - 1) / WARP_T, tilesY = (H + WARP_T - 1) / WARP_T;
   const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);
-  hipLaunchKernelGGL(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
+  RIB_KLAUNCH(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -2623,13 +2664,13 @@ int rib_rasterise(rib_handle* h, int T, int H, int W, const rib_stroke* strokes,
     HeatParams hp;
     hp.peaks = reinterpret_cast<const int32_t*>(ws + L.peaks); hp.w = reinterpret_cast<const double*>(ws + L.weights);
     hp.r = radius; hp.label = labels; hp.T = T; hp.H = H; hp.W = W; hp.nmaps = n_maps; hp.label_nc = 3 + n_maps; hp.ch0 = 3;
-    hipLaunchKernelGGL(k_heatmaps, dim3((H * W + 255) / 256, n_maps, T), dim3(256), 0, st, hp);
+    RIB_KLAUNCH(k_heatmaps, dim3((H * W + 255) / 256, n_maps, T), dim3(256), 0, st, hp);
   }
   SkelParams sp;
   sp.strokes = reinterpret_cast<const RasterStroke*>(ws + L.strokes); sp.colors = reinterpret_cast<const uint32_t*>(ws + L.colors);
   sp.nedges = n_edges; sp.canvas = reinterpret_cast<uint32_t*>(ws + L.canvas); sp.label = labels;
   sp.T = T; sp.H = H; sp.W = W; sp.label_nc = 3 + n_maps; sp.bw = stroke_halfwidth;
-  hipLaunchKernelGGL(k_skeleton, dim3(T), dim3(256), 0, st, sp);
+  RIB_KLAUNCH(k_skeleton, dim3(T), dim3(256), 0, st, sp);
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }
@@ -2650,12 +2691,76 @@ size_t rib_chain_workspace_bytes(rib_handle* h, int T, int B, int H, int W) {
   return PL ? base + align256(PL->ws_bytes) : 0;
 }
 
+// (inside extern "C" an unnamed namespace does not keep a function's name out of the dynamic symbol table: static does)
+static int chain_enqueue(rib_handle* h, int T, int B, int H, int W, const float* key_frame, const float* labels,
+                         const float* dains, float* imgs, float* masks, float* fuses, void* workspace,
+                         size_t workspace_bytes, void* hip_stream);
+
+int rib_set_graph_replay(rib_handle* h, int enable) {
+  if (!h) return RIB_ERR_INVALID;
+  h->graph_replay = enable != 0;
+  if (!h->graph_replay) drop_chain_graphs(h);
+  return RIB_OK;
+}
+
+int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays) {
+  if (!h) return RIB_ERR_INVALID;
+  if (captures) *captures = (int64_t)h->graph_captures;
+  if (replays) *replays = (int64_t)h->graph_replays;
+  return RIB_OK;
+}
+
 int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame, const float* labels,
               const float* dains, float* imgs, float* masks, float* fuses, void* workspace,
               size_t workspace_bytes, void* hip_stream) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (T < 1 || !key_frame || !labels || !dains || !fuses || !workspace) return fail(h, RIB_ERR_INVALID, "rib_chain: bad argument");
+  if (!h->graph_replay || h->profiling || h->device < 0)
+    return chain_enqueue(h, T, B, H, W, key_frame, labels, dains, imgs, masks, fuses, workspace, workspace_bytes, hip_stream);
+  // ---- graph replay: the T x ~130 launches of the segment as ONE graph launch.  Every kernel parameter is a function of the
+  // shape and of the pointers of this call, so that tuple is the key; a call with other tensors captures its own graph (the
+  // enqueue code runs under stream capture, nothing executes), at most 8 are kept.  Same kernels, same parameters, same order
+  // on the same stream: the frames are bit-identical to the launch-by-launch path.
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const std::array<uintptr_t, 12> key = {(uintptr_t)T, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)key_frame, (uintptr_t)labels,
+                                         (uintptr_t)dains, (uintptr_t)imgs, (uintptr_t)masks, (uintptr_t)fuses, (uintptr_t)workspace,
+                                         (uintptr_t)workspace_bytes};
+  for (auto& g : h->chain_graphs)
+    if (g.key == key) {
+      g.used = ++h->graph_clock; ++h->graph_replays;
+      HIP_TRY(h, hipGraphLaunch(g.exec, st));
+      return RIB_OK;
+    }
+  // plans (and the Winograd filter sets they allocate) must exist before the capture starts: building one synchronises
+  if (!get_plan(h, B, H, W, chain_batches_labels(h, T, B) ? PLAN_UNPAIRED : 0)) return RIB_ERR_INVALID;
+  if (chain_batches_labels(h, T, B) && !get_plan(h, T * B, H, W, PLAN_LABELS, B)) return RIB_ERR_INVALID;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  rc = chain_enqueue(h, T, B, H, W, key_frame, labels, dains, imgs, masks, fuses, workspace, workspace_bytes, hip_stream);
+  const hipError_t ec = hipStreamEndCapture(st, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (ec != hipSuccess) return fail(h, RIB_ERR_HIP, fmt("rib_chain: stream capture failed: %s", hipGetErrorString(ec)));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) return fail(h, RIB_ERR_HIP, fmt("rib_chain: graph instantiation failed: %s", hipGetErrorString(ei)));
+  if (h->chain_graphs.size() >= 8) {
+    size_t lru = 0;
+    for (size_t i = 1; i < h->chain_graphs.size(); ++i) if (h->chain_graphs[i].used < h->chain_graphs[lru].used) lru = i;
+    (void)hipGraphExecDestroy(h->chain_graphs[lru].exec);
+    h->chain_graphs.erase(h->chain_graphs.begin() + lru);
+  }
+  h->chain_graphs.push_back({key, exec, ++h->graph_clock});
+  ++h->graph_captures;
+  HIP_TRY(h, hipGraphLaunch(exec, st));
+  return RIB_OK;
+}
+
+static int chain_enqueue(rib_handle* h, int T, int B, int H, int W, const float* key_frame, const float* labels,
+                         const float* dains, float* imgs, float* masks, float* fuses, void* workspace,
+                         size_t workspace_bytes, void* hip_stream) {
+  int rc = RIB_OK;
   // a chain that runs the label-only launches once per segment needs them apart from the image encoder's: the unpaired
   // twin of the frame plan (same kernels and choices: the frames equal rib_forward's bit for bit)
   Plan* P = get_plan(h, B, H, W, chain_batches_labels(h, T, B) ? PLAN_UNPAIRED : 0);
@@ -2701,7 +2806,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
         gp.dst[k] = reinterpret_cast<float4*>(wsb + cp[k].dst);
         gp.n4[k] = (unsigned)(cp[k].bytes / 16);       // every slot is a whole number of 8-channel (32-byte) groups
       }
-      hipLaunchKernelGGL(k_gather6, dim3(1024, 6), dim3(256), 0, st, gp);
+      RIB_KLAUNCH(k_gather6, dim3(1024, 6), dim3(256), 0, st, gp);
     }
     float* img_t = imgs ? imgs + (size_t)t * frame : tmp_img;
     float* mask_t = masks ? masks + (size_t)t * mframe : tmp_mask;
@@ -2723,7 +2828,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
 
 int rib_set_debug_taps(rib_handle* h, int enable) {
   if (!h) return RIB_ERR_INVALID;
-  if (h->keep_taps != (enable != 0)) h->plans.clear();   // the workspace layout depends on it
+  if (h->keep_taps != (enable != 0)) { h->plans.clear(); drop_chain_graphs(h); }   // the workspace layout depends on it
   h->keep_taps = enable != 0;
   return RIB_OK;
 }
@@ -2866,6 +2971,7 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
     if (variant_idx >= kNumVariants || ksplit < 1) return fail(h, RIB_ERR_INVALID, "rib_set_choice: bad variant / ksplit");
     h->choices[key] = {variant_idx, ksplit};
   }
+  drop_chain_graphs(h);
   // the frame plans of this shape (paired and unpaired) are rebuilt on next use, and so are the labels-only plans of
   // chains that follow this shape's choices (key {flags, tuneB, batch, H, W})
   for (auto it = h->plans.begin(); it != h->plans.end();) {
@@ -2913,11 +3019,24 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
   return rc;
 }
 
-int rib_profile_begin(rib_handle* h) {
-  if (!h) return RIB_ERR_INVALID;
+static void drop_prof_events(rib_handle* h) {
   for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
   h->prof_events.clear();
-  h->profiling = true;
+  for (auto& ke : h->prof_kernel_events) { (void)hipEventDestroy(ke.start); (void)hipEventDestroy(ke.stop); }
+  h->prof_kernel_events.clear();
+}
+
+int rib_profile_begin(rib_handle* h) {
+  if (!h) return RIB_ERR_INVALID;
+  drop_prof_events(h);
+  h->profiling = true; h->prof_kernels = false;
+  return RIB_OK;
+}
+
+int rib_profile_begin_kernels(rib_handle* h) {
+  if (!h) return RIB_ERR_INVALID;
+  drop_prof_events(h);
+  h->profiling = true; h->prof_kernels = true;
   return RIB_OK;
 }
 
@@ -2925,6 +3044,17 @@ int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms
   if (!h || !launches || !ms) return RIB_ERR_INVALID;
   h->profiling = false;
   for (int i = 0; i < RIB_KC_COUNT; ++i) { launches[i] = 0; ms[i] = 0.0; }
+  if (h->prof_kernels) {
+    if (!h->prof_kernel_events.empty()) HIP_TRY(h, hipEventSynchronize(h->prof_kernel_events.back().stop));
+    for (const auto& ke : h->prof_kernel_events) {
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, ke.start, ke.stop));
+      launches[ke.kclass] += 1; ms[ke.kclass] += (double)t;
+    }
+    drop_prof_events(h);
+    h->prof_kernels = false;
+    return RIB_OK;
+  }
   if (!h->prof_events.empty()) HIP_TRY(h, hipEventSynchronize(h->prof_events.back().second));
   for (size_t i = 0; i + 1 < h->prof_events.size(); ++i) {
     const int kc = h->prof_events[i].first;
@@ -2933,8 +3063,7 @@ int rib_profile_collect(rib_handle* h, int64_t launches[RIB_KC_COUNT], double ms
     HIP_TRY(h, hipEventElapsedTime(&t, h->prof_events[i].second, h->prof_events[i + 1].second));
     launches[kc] += 1; ms[kc] += (double)t;
   }
-  for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
-  h->prof_events.clear();
+  drop_prof_events(h);
   return RIB_OK;
 }
 

@@ -67,7 +67,9 @@ class Generator:
         self._h = h
         _native.check(h, self._lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1, "f16": 3}[compute_dtype]))
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._tuned: Dict[tuple, int] = {}      # (B,H,W) -> launches whose variant came from the measured table
         self.training = False
+        self._graph_replay = bool(int(__import__("os").environ.get("RIB_GRAPH", "0") or 0))
         self.weights_version = 0        # bumped by load_state_dict / import_weights (Evaluator's lane clones follow it)
         self._warned_copy = False
 
@@ -170,7 +172,7 @@ class Generator:
                 from . import tuning
                 if self._tuning is None:
                     self._tuning = tuning.load(dtype=self.compute_dtype)
-                tuning.apply(self._lib, self._h, self._tuning, B, H, W, dtype=self.compute_dtype)
+                self._tuned[key] = tuning.apply(self._lib, self._h, self._tuning, B, H, W, dtype=self.compute_dtype)
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (B, H, W)):
                 # a stale tuning entry must never break the path: drop it and use the cost model
@@ -259,14 +261,37 @@ class Generator:
                 cache.pop((B, H, W), None)
                 cws = cache[(B, H, W)] = torch.empty(need, dtype=torch.uint8, device=self.device)
             ws = cws
-        fuses = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
-        imgs = torch.empty_like(fuses) if want_all else None
-        masks = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=self.device) if want_all else None
+        if self._graph_replay:
+            # a replayed graph writes where it was captured: two alternating output sets per shape (the previous call's frames
+            # stay valid while the next call runs - a chunked segment reads its `prev` from them), overwritten two calls later
+            ring = self.__dict__.setdefault("_chain_out", {}).setdefault((T, B, H, W, bool(want_all)), {"n": 0, "sets": []})
+            if len(ring["sets"]) < 2:
+                fz = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
+                ring["sets"].append((torch.empty_like(fz) if want_all else None,
+                                     torch.empty((T, B, 1, H, W), dtype=torch.float32, device=self.device) if want_all else None, fz))
+            imgs, masks, fuses = ring["sets"][ring["n"] % len(ring["sets"])] if len(ring["sets"]) == 2 else ring["sets"][-1]
+            ring["n"] += 1
+        else:
+            fuses = torch.empty((T, B, s.image_nc, H, W), dtype=torch.float32, device=self.device)
+            imgs = torch.empty_like(fuses) if want_all else None
+            masks = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=self.device) if want_all else None
         with torch.cuda.device(self.device):
             _native.check(self._h, self._lib.rib_chain(
                 self._h, T, B, H, W, _ptr(key_frame), _ptr(labels), _ptr(dains), _ptr(imgs), _ptr(masks),
                 _ptr(fuses), _ptr(ws), ws.numel(), self._stream()))
         return imgs, masks, fuses
+
+    def set_graph_replay(self, on=True):
+        """rib_chain as ONE HIP graph launch per (shape, tensors): see include/rib.h.  Also on with RIB_GRAPH=1."""
+        _native.check(self._h, self._lib.rib_set_graph_replay(self._h, 1 if on else 0))
+        self._graph_replay = bool(on)
+        self.__dict__.pop("_chain_out", None)
+        return self
+
+    def graph_stats(self):
+        cap, rep = C.c_int64(), C.c_int64()
+        _native.check(self._h, self._lib.rib_graph_stats(self._h, C.byref(cap), C.byref(rep)))
+        return {"captures": cap.value, "replays": rep.value}
 
     # ---- driver-side ops ----------------------------------------------------------------------
     def blend(self, img, mask, dain):
@@ -335,8 +360,10 @@ class Generator:
             out[name.value.decode()] = dst.cpu()
         return out
 
-    def profile_begin(self):
-        _native.check(self._h, self._lib.rib_profile_begin(self._h))
+    def profile_begin(self, kernels=False):
+        """kernels=False: one event in front of every launch (the classes add up to the profiled step, event cost included);
+        kernels=True: a (start, stop) pair bound to every dispatch - the kernels' own execution times, as rocprofv3 reports them."""
+        _native.check(self._h, (self._lib.rib_profile_begin_kernels if kernels else self._lib.rib_profile_begin)(self._h))
 
     def profile_collect(self):
         n = len(_native.KC_NAMES)
@@ -349,6 +376,11 @@ class Generator:
         fl = (C.c_double * n)()
         _native.check(self._h, self._lib.rib_forward_flops(self._h, B, H, W, fl))
         return {k: float(fl[i]) for i, k in enumerate(_native.KC_NAMES)}
+
+    def tuned_ops(self, B, H, W):
+        """How many launches of this shape run a measured choice (0: the analytic cost model decides everything)."""
+        self._workspace(B, H, W)
+        return self._tuned.get((B, H, W), 0)
 
     def num_launches(self, B, H, W):
         return self._lib.rib_num_launches(self._h, B, H, W)

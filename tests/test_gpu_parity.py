@@ -631,6 +631,41 @@ def test_chain_with_batched_label_work_matches_the_per_frame_chain(monkeypatch):
         assert float((f1[t].cpu() - prev).abs().max()) < TOL, t
 
 
+def test_chain_graph_replay_is_bit_identical():
+    """rib_chain as ONE HIP graph launch.  The first call with a given shape and set of tensors captures
+    the segment's launches, later calls replay the graph: same kernels, parameters and order, so the frames equal the
+    launch-by-launch path bit for bit - also with batch 2, other inputs in the same tensors, and after the option is
+    switched off again.  Generator.chain alternates two output sets while the option is on: 2 captures, then replays."""
+    spec, sd, G = build("full", 0)
+    T, B, H, W = 4, 2, 64, 96
+    labels = torch.stack([synth.make_inputs(spec, B, H, W, 60 + t)[0] for t in range(T)]).cuda()
+    dains = torch.stack([synth.make_inputs(spec, B, H, W, 60 + t)[1] for t in range(T)]).cuda()
+    key = synth.make_inputs(spec, B, H, W, 59)[2].cuda()
+    want = [t.clone() for t in G.chain(key, labels, dains)]
+    G.set_graph_replay(True)
+    try:
+        for k in range(5):
+            got = G.chain(key, labels, dains)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(want, got)), k
+        st = G.graph_stats()
+        assert st == {"captures": 2, "replays": 3}, st
+        # new values in the SAME input tensors: the replayed graph reads them (nothing was baked in but addresses)
+        labels2 = torch.stack([synth.make_inputs(spec, B, H, W, 80 + t)[0] for t in range(T)]).cuda()
+        keep = labels.clone()
+        labels.copy_(labels2)
+        got2 = [t.clone() for t in G.chain(key, labels, dains)]
+        assert G.graph_stats()["replays"] == 4
+        G.set_graph_replay(False)
+        want2 = G.chain(key, labels, dains)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(want2, got2))
+        assert not torch.equal(want2[2], want[2])
+        labels.copy_(keep)
+    finally:
+        G.set_graph_replay(False)
+
+
 def test_full_size_properties_512():
     """Size-independent properties at BASELINE.json's full size (512x512), where the oracle is only run once:
     batch independence (a sample's frame does not depend on its batch mates), determinism, label_prev is dead,
