@@ -137,6 +137,8 @@ def main():
     graph_on = args.graph or bool(int(os.environ.get("RIB_GRAPH", "0") or 0))
     if graph_on:
         G.set_graph_replay(True)
+        torch.cuda.synchronize(dev)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))      # the NULL stream cannot be captured
     # extra in-flight lanes: clones of the generator (same folded weight blob) on their own streams
     lanes = [(G, torch.cuda.current_stream(dev))]
     if args.inflight > 1:

@@ -224,7 +224,8 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
 /* ---- graph replay of rib_chain (no reference counterpart; a host-side option).  With it on (or RIB_GRAPH=1 in the
  * environment at rib_create), the first rib_chain call with a given (T,B,H,W) AND a given set of pointers captures the
  * segment's launches into one HIP graph and every later call with the same arguments is ONE hipGraphLaunch on the
- * caller's stream; calls with other tensors capture their own graph (at most 8 are kept, least recently used first out).
+ * caller's stream (which must not be the NULL stream - that one cannot be captured and keeps the launch-by-launch
+ * path); calls with other tensors capture their own graph (at most 8 are kept, least recently used first out).
  * Same kernels, parameters and order: frames are bit-identical to the launch-by-launch path (tested).  Meant for hosts
  * that drive many GPUs from few cores, where enqueueing ~130 launches per frame per GPU becomes the limiter.
  * rib_graph_stats: how many calls captured / replayed since rib_create. ---- */

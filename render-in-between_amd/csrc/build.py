@@ -3,9 +3,9 @@
     python render-in-between_amd/csrc/build.py [--force] [--jobs N] [--check]
 
 hipcc cross-compiles without a GPU; the built .so files are git-ignored but travel to the GPU box with
-the gpurun snapshot.  librib.so is linked from rib.o (runtime, C ABI, the small kernels) and eight
+the gpurun snapshot.  librib.so is linked from rib.o (runtime, C ABI, the small kernels) and RIB_NSECTIONS (variants.hip.h: 24)
 igemm_shard_<s>.o objects, each holding one section of the k_igemm tile variants (variants.def): the
-kernel instantiations dominate the build and compile as parallel jobs.
+kernel instantiations dominate the build and compile as a queue of parallel jobs (about 2 min on 8 cores).
 
 Build stamps.  Every object is compiled with -DRIB_BUILD_STAMP="<hash>" where <hash> is the sha256 over the CONTENT
 of the sources that object is made from plus the compiler flags and the compiler's version line, and keeps it as a
@@ -13,7 +13,7 @@ string ("rib-stamp <tag> <hash>").  An object is rebuilt when the stamp it carri
 (content, not mtime: a `git checkout` or a touched file cannot leave a stale object behind), the library is re-linked
 when it does not carry exactly the objects' stamps, and `rib_build_info()` (include/rib.h) reports them at run time:
 bench.py prints the string in its JSON line and tests/test_native_host.py asserts stamp(librib.so) == stamp(tree) for
-all nine objects, so a measured binary that the tracked source does not build cannot go unnoticed.
+all objects, so a measured binary that the tracked source does not build cannot go unnoticed.
 `--check` prints the tree's and the library's stamps and exits 1 on a mismatch without building.
 """
 import hashlib
@@ -27,7 +27,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 INC = os.path.join(HERE, "..", "..", "include")
 OBJ = os.path.join(HERE, "build")
-NSECTIONS = 8
+
+
+def _nsections():
+    with open(os.path.join(HERE, "variants.hip.h")) as f:
+        return int(re.search(r"#define RIB_NSECTIONS (\d+)", f.read()).group(1))
+
+
+NSECTIONS = _nsections()        # shard objects (variants.hip.h); more than cores: the compiles run as a job queue
 SRC = os.path.join(HERE, "rib.hip")
 SHARD_SRC = os.path.join(HERE, "igemm_shard.hip")
 SHARD_DEPS = [SHARD_SRC] + [os.path.join(HERE, f) for f in ("kernels.hip.h", "variants.hip.h", "variants.def")]
@@ -135,8 +142,9 @@ def build(force=False, verbose=True, jobs=None):
         o = os.path.join(OBJ, "igemm_shard_%d.o" % s)
         objs.append(o)
         if force or embedded_stamps(o).get("shard%d" % s) != want["shard%d" % s]:
-            work.append((SHARD_SRC, o, _stamp_def(want["shard%d" % s]) + ["-DRIB_SECTION=%d" % s]))
+            work.append((SHARD_SRC, o, _stamp_def(want["shard%d" % s]) + ["-DRIB_SECTION=%d" % s, "-DRIB_ON_%d=RIB_KEEP" % s]))
     if work:
+        work.sort(key=lambda w: w[0] != SRC)          # rib.o first: it is the longest single compile
         jobs = jobs or max(1, min(len(work), os.cpu_count() or 1))
         with ThreadPoolExecutor(jobs) as ex:
             for f in [ex.submit(_compile_obj, s, o, d, verbose) for s, o, d in work]:

@@ -1,5 +1,5 @@
 // igemm_shard.hip - one section of the k_igemm tile variants (variants.def), compiled once per section
-// with -DRIB_SECTION=<0..7> so that the kernel code generation runs as parallel hipcc jobs.
+// with -DRIB_SECTION=<s> -DRIB_ON_<s>=RIB_KEEP (s < RIB_NSECTIONS, variants.hip.h) so that the kernel code generation runs as parallel hipcc jobs.
 // Taking a kernel's address instantiates it in this object; rib.hip refers to it through `extern template`.
 #define RIB_IGEMM_ONLY 1
 #include "kernels.hip.h"
@@ -13,40 +13,81 @@
 #define RIB_CAT(a, b) RIB_CAT_(a, b)
 #define RIB_KEEP(...) __VA_ARGS__
 #define RIB_DROP(...)
-// RIB_ON_<s> keeps its arguments only for this object's section
+// RIB_ON_<s> keeps its arguments only for this object's section: the build defines RIB_ON_<RIB_SECTION> as RIB_KEEP on the
+// command line, every other section's selector falls back to RIB_DROP here
+#ifndef RIB_ON_0
 #define RIB_ON_0 RIB_DROP
+#endif
+#ifndef RIB_ON_1
 #define RIB_ON_1 RIB_DROP
+#endif
+#ifndef RIB_ON_2
 #define RIB_ON_2 RIB_DROP
+#endif
+#ifndef RIB_ON_3
 #define RIB_ON_3 RIB_DROP
+#endif
+#ifndef RIB_ON_4
 #define RIB_ON_4 RIB_DROP
+#endif
+#ifndef RIB_ON_5
 #define RIB_ON_5 RIB_DROP
+#endif
+#ifndef RIB_ON_6
 #define RIB_ON_6 RIB_DROP
+#endif
+#ifndef RIB_ON_7
 #define RIB_ON_7 RIB_DROP
-#if RIB_SECTION == 0
-#undef RIB_ON_0
-#define RIB_ON_0 RIB_KEEP
-#elif RIB_SECTION == 1
-#undef RIB_ON_1
-#define RIB_ON_1 RIB_KEEP
-#elif RIB_SECTION == 2
-#undef RIB_ON_2
-#define RIB_ON_2 RIB_KEEP
-#elif RIB_SECTION == 3
-#undef RIB_ON_3
-#define RIB_ON_3 RIB_KEEP
-#elif RIB_SECTION == 4
-#undef RIB_ON_4
-#define RIB_ON_4 RIB_KEEP
-#elif RIB_SECTION == 5
-#undef RIB_ON_5
-#define RIB_ON_5 RIB_KEEP
-#elif RIB_SECTION == 6
-#undef RIB_ON_6
-#define RIB_ON_6 RIB_KEEP
-#elif RIB_SECTION == 7
-#undef RIB_ON_7
-#define RIB_ON_7 RIB_KEEP
-#else
+#endif
+#ifndef RIB_ON_8
+#define RIB_ON_8 RIB_DROP
+#endif
+#ifndef RIB_ON_9
+#define RIB_ON_9 RIB_DROP
+#endif
+#ifndef RIB_ON_10
+#define RIB_ON_10 RIB_DROP
+#endif
+#ifndef RIB_ON_11
+#define RIB_ON_11 RIB_DROP
+#endif
+#ifndef RIB_ON_12
+#define RIB_ON_12 RIB_DROP
+#endif
+#ifndef RIB_ON_13
+#define RIB_ON_13 RIB_DROP
+#endif
+#ifndef RIB_ON_14
+#define RIB_ON_14 RIB_DROP
+#endif
+#ifndef RIB_ON_15
+#define RIB_ON_15 RIB_DROP
+#endif
+#ifndef RIB_ON_16
+#define RIB_ON_16 RIB_DROP
+#endif
+#ifndef RIB_ON_17
+#define RIB_ON_17 RIB_DROP
+#endif
+#ifndef RIB_ON_18
+#define RIB_ON_18 RIB_DROP
+#endif
+#ifndef RIB_ON_19
+#define RIB_ON_19 RIB_DROP
+#endif
+#ifndef RIB_ON_20
+#define RIB_ON_20 RIB_DROP
+#endif
+#ifndef RIB_ON_21
+#define RIB_ON_21 RIB_DROP
+#endif
+#ifndef RIB_ON_22
+#define RIB_ON_22 RIB_DROP
+#endif
+#ifndef RIB_ON_23
+#define RIB_ON_23 RIB_DROP
+#endif
+#if RIB_SECTION < 0 || RIB_SECTION >= RIB_NSECTIONS
 #error "RIB_SECTION out of range"
 #endif
 

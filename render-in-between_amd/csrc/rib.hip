@@ -80,8 +80,9 @@ namespace { struct ProfPair { hipEvent_t start = nullptr, stop = nullptr; }; thr
 #endif
 // the stamp strings of the eight k_igemm shard objects (igemm_shard.hip) and this object's own
 extern "C" {
-extern const char rib_stamp_section_0[], rib_stamp_section_1[], rib_stamp_section_2[], rib_stamp_section_3[],
-    rib_stamp_section_4[], rib_stamp_section_5[], rib_stamp_section_6[], rib_stamp_section_7[];
+#define RIB_X(s) extern const char rib_stamp_section_##s[];
+RIB_FOR_SECTIONS(RIB_X)
+#undef RIB_X
 }
 extern "C" __attribute__((used, visibility("hidden"))) const char kLibStamp[] = "rib-stamp lib " RIB_BUILD_STAMP;
 
@@ -2716,7 +2717,8 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
   int rc = check_ready(h);
   if (rc) return rc;
   if (T < 1 || !key_frame || !labels || !dains || !fuses || !workspace) return fail(h, RIB_ERR_INVALID, "rib_chain: bad argument");
-  if (!h->graph_replay || h->profiling || h->device < 0)
+  // (the NULL stream cannot be captured: a caller on it gets the launch-by-launch path)
+  if (!h->graph_replay || h->profiling || h->device < 0 || hip_stream == nullptr)
     return chain_enqueue(h, T, B, H, W, key_frame, labels, dains, imgs, masks, fuses, workspace, workspace_bytes, hip_stream);
   // ---- graph replay: the T x ~130 launches of the segment as ONE graph launch.  Every kernel parameter is a function of the
   // shape and of the pointers of this call, so that tuple is the key; a call with other tensors captures its own graph (the
@@ -2919,9 +2921,9 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|%s 16x16 tile, %d output channels%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
   else if (op.kind == OP_IGEMM)
-    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
+    snprintf(buf, buflen, "%s|%d|%u,%u,%u|tile %dx%d BN %d BK %d s%d k%d ups%d ksplit%d kw%d tb%d%s v%d|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->TH(), op.var->TW(), op.var->BN(), op.var->BK, op.var->STRIDE, op.var->KS, (int)op.var->UPS, op.ip.ksplit, op.var->KW, op.var->DMAK ? 100 + (op.var->TB == 9 ? 9 : 0) : op.var->TB,
-             op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
+             op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", (int)(op.var - kVariants), op.flops);      // (v<n>: index into rib_variant_info)
   else if (op.kind == OP_GEMM)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|gemm (LDS-DMA staged operands) tile %dx%d BK 32, %d x [%d x %d x %d]%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.var->BM(), op.var->BN(), (int)op.grid.z, op.gp.M, op.gp.N, op.gp.K, op.wino ? (op.wino_m == 4 ? " wino4" : " wino") : "", op.flops);
@@ -2937,11 +2939,12 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
 // shape, and time a single op of the plan in isolation ----
 const char* rib_build_info(void) {
   static const std::string info = [] {
-    const char* sh[8] = {rib_stamp_section_0, rib_stamp_section_1, rib_stamp_section_2, rib_stamp_section_3,
-                         rib_stamp_section_4, rib_stamp_section_5, rib_stamp_section_6, rib_stamp_section_7};
+#define RIB_X(s) rib_stamp_section_##s,
+    const char* sh[RIB_NSECTIONS] = {RIB_FOR_SECTIONS(RIB_X)};
+#undef RIB_X
     std::string s = std::string("librib stamp=") + (kLibStamp + sizeof("rib-stamp lib ") - 1) + " shards=";
     bool ok = true;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RIB_NSECTIONS; ++i) {
       const char* hash = strrchr(sh[i], ' ');          // "rib-stamp shard<i> <hash>"
       hash = hash ? hash + 1 : "?";
       ok = ok && strcmp(hash, RIB_SHARD_STAMP) == 0;

@@ -6,6 +6,13 @@
 // rib.hip's RIB_V / RIB_VK / ... table macros name the same instantiations; keep the two in step.
 #pragma once
 
+// The entries of variants.def are dealt to RIB_NSECTIONS shard objects (igemm_shard.hip compiled once per section with
+// -DRIB_SECTION=<s> -DRIB_ON_<s>=RIB_KEEP; csrc/build.py reads the count from this line and runs the compiles as a job queue:
+// more sections than cores, so that the few slow entries - the fully unrolled phase convolutions - do not make one object the
+// long pole of the build).
+#define RIB_NSECTIONS 24
+#define RIB_FOR_SECTIONS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+
 // template parameters of k_igemm: FRW, WM, WN, MF, NF, BK, STRIDE, KS, UPS, SPADE, PREC (0 fp32 / 1 bf16 / 2 half; false = 0), AUX, PRO, KW, TB, DMA
 #define RIB_F_EXTERN(...) extern template __global__ void rib::k_igemm<__VA_ARGS__>(const rib::IgemmParams);
 #define RIB_F_TOUCH(...) &rib::k_igemm<__VA_ARGS__>,

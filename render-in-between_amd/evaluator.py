@@ -35,8 +35,7 @@ from typing import List
 import numpy as np
 import torch
 
-from . import rasterise
-from .resize import resize_cubic_u8
+from . import io_worker, rasterise
 
 
 def sample_rate_of(num_pose: int, num_key: int) -> int:
@@ -57,12 +56,37 @@ def split_segments(seq_len: int, sample_rate: int):
     return keys, segs
 
 
+_PROC_POOLS = {}
+
+
+def _process_pool(n):
+    """One pool of n worker processes per size for the whole process (Evaluators come and go; 32 interpreters should not).
+    forkserver: the workers are forked from a clean server process that never saw the GPU (a plain fork of a process with
+    an initialised HIP runtime is not safe), with this package's file-side module preloaded so that a fork is cheap."""
+    pool = _PROC_POOLS.get(n)
+    if pool is None:
+        import atexit
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["render_in_between_amd.io_worker", "PIL.Image", "PIL.PngImagePlugin", "scipy.optimize"])
+        pool = _PROC_POOLS[n] = ProcessPoolExecutor(n, mp_context=ctx)
+        list(pool.map(_warm, range(n)))          # start them all now, not under the first clip
+        atexit.register(pool.shutdown, wait=False, cancel_futures=True)
+    return pool
+
+
+def _warm(_):
+    return io_worker.warm()
+
+
 def _list(d, exts):
     return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(exts)]
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=8, io_threads=None):
+    def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=8, io_threads=None,
+                 io_mode="process"):
         """batch: independent segments of equal length rendered as ONE chain of that batch size (None: by frame size,
         `default_batch`; 1: every segment on its own, the round-1..3 behaviour).  Per-sample arithmetic does not depend
         on the other samples of a batch, but a batch-B plan may pick other tile variants / split-K factors than the
@@ -71,13 +95,20 @@ class Evaluator:
         lanes: independent chains kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (the frames inside a segment stay strictly sequential).
         io_threads: decode / encode workers (None: the CPUs this process may run on, divided by the ranks of the job
-        sharing the host, at most 32).
+        sharing the host, at most 48).
+        io_mode: "process" (default) runs the file-side work of the native pipeline - decode, json -> rasteriser tables,
+        PNG encode - in a pool of worker processes shared by all Evaluators of this process (io_worker.py), so that it
+        cannot hold the interpreter lock of the thread that enqueues the GPU work; "thread": a thread pool (rounds 1-3).
+        A model that only speaks the reference's call protocol, or a label_fn, always uses threads.
         label_fn(frames, H, W) -> [T, 22, H, W]: rasteriser override for models that only speak the
         reference's call protocol (the tests pass the CPU oracle); by default the model's GPU
         rasteriser is used and a model without one is an error (no host fallback).
         resize: "cv2" = OpenCV INTER_CUBIC restated (resize.py; what the reference's A.Resize computes), "pil" = PIL BICUBIC."""
         if resize not in ("cv2", "pil"):
             raise ValueError("resize must be 'cv2' or 'pil'")
+        if io_mode not in ("process", "thread"):
+            raise ValueError("io_mode must be 'process' or 'thread'")
+        self.io_mode = io_mode
         self.resize = resize
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
@@ -94,7 +125,7 @@ class Evaluator:
         # N ranks on one host share its cores: LOCAL_WORLD_SIZE (torchrun) or WORLD_SIZE ranks each take their part, and one
         # core per rank stays with the launch thread (5 k launches per 31-frame segment); more workers than cores only slow it
         ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-        self.io_threads = max(1, int(io_threads)) if io_threads else max(1, min(32, ncpu // ranks - 1))
+        self.io_threads = max(1, int(io_threads)) if io_threads else max(1, min(48, ncpu // ranks - 1))
         self._pool = None                                   # created on first use, kept across calls (thread start-up is ~2 ms each)
         self._finishers = None
         self.timings = {}                                   # seconds per phase of the last evaluate_from_folder
@@ -150,14 +181,7 @@ class Evaluator:
         """PIL decode -> RGB uint8 HWC at the model size.  `resize="cv2"` (default): OpenCV's 8-bit INTER_CUBIC restated
         in resize.py (what the reference's albumentations `A.Resize(interpolation=cv2.INTER_CUBIC)` computes: A = -0.75,
         no low-pass on reduction; unpinned, cv2 is not in this image); `resize="pil"`: PIL's BICUBIC (round 1)."""
-        from PIL import Image
-        img = Image.open(path).convert("RGB")
-        w0, h0 = img.size
-        if (w0, h0) == (self.width, self.height):
-            return np.asarray(img, dtype=np.uint8), (w0, h0)
-        if self.resize == "pil":
-            return np.asarray(img.resize((self.width, self.height), Image.BICUBIC), dtype=np.uint8), (w0, h0)
-        return resize_cubic_u8(np.asarray(img, dtype=np.uint8), self.width, self.height), (w0, h0)
+        return io_worker.decode_resized_u8(path, self.width, self.height, self.resize)
 
     def load_image(self, path):
         """PIL open -> resize to the model size (cubic) -> [-1,1] CHW (ToTensor + Normalize(.5,.5));
@@ -175,10 +199,7 @@ class Evaluator:
     def load_pose(self, json_path, orig_size):
         """json -> (landmarks, conf) in model-size pixels: the keypoints follow the image resize
         (A.Resize keypoint rule, evaluator.py:24-26,219)."""
-        pose = rasterise.read_json_keypoint(json_path)
-        sx, sy = self.width / orig_size[0], self.height / orig_size[1]
-        lm = [(pose[i, 0] * sx, pose[i, 1] * sy) for i in range(pose.shape[0])]
-        return lm, [pose[i, 2] for i in range(pose.shape[0])]
+        return io_worker.scaled_pose(json_path, orig_size, self.width, self.height)
 
     def make_labels(self, model, frames):
         """[(landmarks, conf)] -> [T, 22, H, W] label maps: 3-ch skeleton image in [-1,1] + 19
@@ -219,7 +240,6 @@ class Evaluator:
         pool, finishers = self._pool, self._finishers
         native = hasattr(model, "chain") and hasattr(model, "quantise")
         gpu_labels = native and self.label_fn is None and hasattr(model, "rasterise")
-        kw = {} if self.png_compress_level is None else {"compress_level": int(self.png_compress_level)}
         sizes = {}
 
         def image_size(path):                                 # header only; the keypoints scale with THIS image (below)
@@ -228,14 +248,17 @@ class Evaluator:
                     sizes[path] = im.size
             return sizes[path]
 
+        procs = _process_pool(self.io_threads) if (native and self.io_mode == "process") else None
+        level = self.png_compress_level
+
+        def save_q(q, name):                                  # uint8 HWC -> file, here or in a worker process
+            if procs is not None:
+                return procs.submit(io_worker.save_png, q, name, level).result()
+            return io_worker.save_png(q, name, level)
+
         def save_host(x, name):                               # utils/utils.py:129-142 on the host
             a = np.transpose(x[0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
-            Image.fromarray((np.clip(a, 0, 1) * 255.0).astype(np.uint8)).save(name, **kw)
-            return name
-
-        def save_q(q, name):
-            Image.fromarray(q).save(name, **kw)
-            return name
+            return save_q((np.clip(a, 0, 1) * 255.0).astype(np.uint8), name)
 
         t_wall = time.perf_counter()
         up = None
@@ -297,6 +320,29 @@ class Evaluator:
                 if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
                     pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
                 return dain, gt, pose
+
+            def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
+                """The same pre-load in a worker process; its result is unpacked (the DAIN frame copied into its pinned staging
+                slot, arrays wrapped as tensors) by the pool's result thread as soon as it arrives."""
+                from concurrent.futures import Future
+                ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
+                src = procs.submit(io_worker.load_frame, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0, gpu_labels,
+                                   self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
+                out = Future()
+
+                def unpack(f):
+                    try:
+                        dain, gt, pose = f.result()
+                        dain = torch.from_numpy(dain)
+                        if i in slot:
+                            ui, t, b = slot[i]
+                            stage[ui][t, b].copy_(dain)
+                            dain = None
+                        out.set_result((dain, torch.from_numpy(gt) if gt is not None else None, pose))
+                    except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
+                        out.set_exception(e)
+                src.add_done_callback(unpack)
+                return out
             keys = my_keys
             if native:
                 # decode in the order the launch thread will ask for the frames: unit by unit, the unit's key frames first
@@ -308,7 +354,7 @@ class Evaluator:
                 order += [k for k in keys if k not in seen]
             else:
                 order = sorted(set(my_keys) | {i for _, frames in segs for i in frames})
-            loads = {i: pool.submit(load, i) for i in order}                       # FIFO
+            loads = {i: (load_in_worker(i) if procs is not None else pool.submit(load, i)) for i in order}      # FIFO
             ngroups = len({u[0] for u in units})
             lanes = self._lanes(model, ngroups) if native else None
             futs = {}
@@ -362,6 +408,9 @@ class Evaluator:
                 def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd)):
                     done.synchronize()
                     qn = pinned.numpy()
+                    if procs is not None:
+                        fs = [procs.submit(io_worker.save_png, qn[j], names[out_frames[j]], level) for j in range(len(out_frames))]
+                        return [f.result() for f in fs]
                     return list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
                 seg_fut = finishers.submit(finish)
                 for j, i in enumerate(out_frames):

@@ -273,3 +273,30 @@ def test_group_segments_batches_equal_lengths_only():
     assert ev.Evaluator(cfg).default_batch() == 8
     cfg.model_height = cfg.model_width = 512
     assert ev.Evaluator(cfg).default_batch() == 4
+
+
+def test_io_worker_processes_return_what_the_threads_compute(tmp_path):
+    """The file-side work of the native pipeline runs in forkserver worker processes (io_worker.py): same functions, same
+    results as in-process calls - decoded frame, normalised key frame, rasteriser tables - and PNG bytes equal to PIL's own."""
+    from PIL import Image
+    from render_in_between_amd import io_worker
+    root = str(tmp_path)
+    _write_example(root, n_key=2, rate=2)
+    dain = os.path.join(root, "DAIN", "clipA", "f001.png")
+    key = os.path.join(root, "inputs", "clipA", "0000.png")
+    pose = os.path.join(root, "Predict_motion", "clipA", "f001_keypoints.json")
+    args = (dain, key, pose, True, True, 48, 32, "cv2", 0.001, 0.001)
+    want = io_worker.load_frame(*args)
+    pool = ev._process_pool(2)
+    assert ev._process_pool(2) is pool                      # one pool per size and process
+    got = pool.submit(io_worker.load_frame, *args).result()
+    assert np.array_equal(got[0], want[0]) and got[0].dtype == np.uint8 and got[0].shape == (32, 48, 3)
+    assert np.array_equal(got[1], want[1]) and got[1].dtype == np.float32 and got[1].shape == (3, 32, 48)
+    assert all(np.array_equal(a, b) for a, b in zip(got[2], want[2]))
+    E = ev.Evaluator(rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48))
+    assert torch.equal(E.load_image(key)[0], torch.from_numpy(want[1]))
+    out = os.path.join(root, "w.png")
+    assert pool.submit(io_worker.save_png, want[0], out, None).result() == out
+    ref = os.path.join(root, "r.png")
+    Image.fromarray(want[0]).save(ref)
+    assert open(out, "rb").read() == open(ref, "rb").read()

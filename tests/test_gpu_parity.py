@@ -642,26 +642,30 @@ def test_chain_graph_replay_is_bit_identical():
     dains = torch.stack([synth.make_inputs(spec, B, H, W, 60 + t)[1] for t in range(T)]).cuda()
     key = synth.make_inputs(spec, B, H, W, 59)[2].cuda()
     want = [t.clone() for t in G.chain(key, labels, dains)]
+    torch.cuda.synchronize()
     G.set_graph_replay(True)
+    side = torch.cuda.Stream()          # (the NULL stream cannot be captured)
     try:
-        for k in range(5):
-            got = G.chain(key, labels, dains)
+        with torch.cuda.stream(side):
+            for k in range(5):
+                got = G.chain(key, labels, dains)
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(want, got)), k
+            st = G.graph_stats()
+            assert st == {"captures": 2, "replays": 3}, st
+            # new values in the SAME input tensors: the replayed graph reads them (nothing was baked in but addresses)
+            labels2 = torch.stack([synth.make_inputs(spec, B, H, W, 80 + t)[0] for t in range(T)]).cuda()
+            keep = labels.clone()
+            labels.copy_(labels2)
+            got2 = [t.clone() for t in G.chain(key, labels, dains)]
+            assert G.graph_stats()["replays"] == 4
+            G.set_graph_replay(False)
+            want2 = G.chain(key, labels, dains)
             torch.cuda.synchronize()
-            assert all(torch.equal(a, b) for a, b in zip(want, got)), k
-        st = G.graph_stats()
-        assert st == {"captures": 2, "replays": 3}, st
-        # new values in the SAME input tensors: the replayed graph reads them (nothing was baked in but addresses)
-        labels2 = torch.stack([synth.make_inputs(spec, B, H, W, 80 + t)[0] for t in range(T)]).cuda()
-        keep = labels.clone()
-        labels.copy_(labels2)
-        got2 = [t.clone() for t in G.chain(key, labels, dains)]
-        assert G.graph_stats()["replays"] == 4
-        G.set_graph_replay(False)
-        want2 = G.chain(key, labels, dains)
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(want2, got2))
-        assert not torch.equal(want2[2], want[2])
-        labels.copy_(keep)
+            assert all(torch.equal(a, b) for a, b in zip(want2, got2))
+            assert not torch.equal(want2[2], want[2])
+            labels.copy_(keep)
+            torch.cuda.synchronize()
     finally:
         G.set_graph_replay(False)
 

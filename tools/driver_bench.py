@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=8)
     ap.add_argument("--io-threads", type=int, default=0)
     ap.add_argument("--compress", type=int, default=-1, help="PNG compress level (-1: PIL's default, 6, as the reference)")
+    ap.add_argument("--io-mode", default="process", choices=("process", "thread"))
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
     with tempfile.TemporaryDirectory() as root:
         n = write_clip(root, a.keys, a.rate, H, W)
         E = ev.Evaluator(cfg, lanes=a.lanes, batch=a.batch or None, chunk=a.chunk, io_threads=a.io_threads or None,
-                         png_compress_level=None if a.compress < 0 else a.compress)
+                         png_compress_level=None if a.compress < 0 else a.compress, io_mode=a.io_mode)
         dirs = [os.path.join(root, d) for d in ("inputs", "DAIN", "Predict_motion")]
         walls = []
         for rep in range(1 + a.reps):           # the first run also builds launch plans and pools: not counted
@@ -77,7 +78,7 @@ def main():
     gen = n - a.keys
     wall = sorted(walls[1:])[len(walls[1:]) // 2]
     print(json.dumps({"height": H, "width": W, "dtype": a.dtype, "frames": n, "generated": gen, "lanes": a.lanes,
-                      "batch": a.batch or E.default_batch(), "chunk": a.chunk, "io_threads": E.io_threads,
+                      "batch": a.batch or E.default_batch(), "chunk": a.chunk, "io_threads": E.io_threads, "io_mode": a.io_mode,
                       "cpus": len(os.sched_getaffinity(0)), "png_compress_level": a.compress,
                       "wall_s": wall, "wall_s_runs": [round(w, 4) for w in walls[1:]], "frames_per_s_end_to_end": n / wall,
                       "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units")},
