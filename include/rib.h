@@ -160,7 +160,8 @@ int rib_quantise(rib_handle* h, int B, int C, int H, int W, const float* img_nch
  * line was fitted with the roles of x and y exchanged.  n = 0: limb not drawn.
  * peaks: (x, y) = (int(x), int(y)) of each joint's one-hot, x = -1 when the joint is off.
  * weights: the radius+1 half of scipy's normalised gaussian kernel (weights[d] = tap +-d).
- * All four tables are HOST pointers (a few KB per frame; copied into the workspace on `stream`). */
+ * All four tables are HOST pointers (a few KB per frame): they are copied into page-locked staging memory of the handle
+ * before the call returns and go to the workspace in one asynchronous copy on `stream` - the call only enqueues. */
 typedef struct rib_stroke {
   int32_t n, swap;
   double start, step, stop, a, b;

@@ -37,8 +37,8 @@ def _nsections():
 NSECTIONS = _nsections()        # shard objects (variants.hip.h); more than cores: the compiles run as a job queue
 SRC = os.path.join(HERE, "rib.hip")
 SHARD_SRC = os.path.join(HERE, "igemm_shard.hip")
-SHARD_DEPS = [SHARD_SRC] + [os.path.join(HERE, f) for f in ("kernels.hip.h", "variants.hip.h", "variants.def")]
-DEPS = [SRC, os.path.join(HERE, "raster.hip.h"), os.path.join(INC, "rib.h")] + SHARD_DEPS[1:]
+SHARD_DEPS = [SHARD_SRC] + [os.path.join(HERE, f) for f in ("igemm.hip.h", "variants.hip.h", "variants.def")]
+DEPS = [SRC, os.path.join(HERE, "kernels.hip.h"), os.path.join(HERE, "raster.hip.h"), os.path.join(INC, "rib.h")] + SHARD_DEPS[1:]
 OUT = os.path.join(HERE, "librib.so")
 # stage 1 (motion transformer, include/rib_motion.h) is its own small library
 MOTION_SRC = os.path.join(HERE, "motion.hip")

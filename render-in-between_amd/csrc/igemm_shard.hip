@@ -1,8 +1,7 @@
 // igemm_shard.hip - one section of the k_igemm tile variants (variants.def), compiled once per section
 // with -DRIB_SECTION=<s> -DRIB_ON_<s>=RIB_KEEP (s < RIB_NSECTIONS, variants.hip.h) so that the kernel code generation runs as parallel hipcc jobs.
 // Taking a kernel's address instantiates it in this object; rib.hip refers to it through `extern template`.
-#define RIB_IGEMM_ONLY 1
-#include "kernels.hip.h"
+#include "igemm.hip.h"
 #include "variants.hip.h"
 
 #ifndef RIB_SECTION

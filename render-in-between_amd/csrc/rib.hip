@@ -627,6 +627,11 @@ struct rib_handle {
   std::vector<ChainGraph> chain_graphs;
   bool graph_replay = false;
   uint64_t graph_clock = 0, graph_captures = 0, graph_replays = 0;
+  // rib_rasterise: page-locked staging for the host tables (two slots; a slot is reused once the copy out of it has completed,
+  // which its event says), so that the call only enqueues - the caller's pageable arrays are free again on return
+  struct RasterStage { char* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
+  RasterStage raster_stage[2];
+  int raster_next = 0;
   bool profiling = false;
   bool prof_kernels = false;   // rib_profile_begin_kernels: (start, stop) pairs bound to the dispatches instead of interval events
   std::vector<std::pair<int, hipEvent_t>> prof_events;   // (class of the launch behind the event, -1: end of a plan run)
@@ -2278,6 +2283,7 @@ int rib_create(const rib_config* cfg, int device, rib_handle** out) {
 void rib_destroy(rib_handle* h) {
   if (!h) return;
   drop_chain_graphs(h);
+  for (auto& rs : h->raster_stage) { if (rs.host) (void)hipHostFree(rs.host); if (rs.done) (void)hipEventDestroy(rs.done); }
   if (h->d_blob) (void)hipFree(h->d_blob);
   free_wino_sets(h);
   for (auto& pe : h->prof_events) (void)hipEventDestroy(pe.second);
@@ -2649,18 +2655,35 @@ int rib_rasterise(rib_handle* h, int T, int H, int W, const rib_stroke* strokes,
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   char* ws = reinterpret_cast<char*>(workspace);
   HIP_TRY(h, hipSetDevice(h->device));
-  std::vector<uint32_t> packed(n_edges);
-  if (n_edges > 0) {
-    for (int e = 0; e < n_edges; ++e)
-      packed[e] = (uint32_t)colors_rgb[3 * e] | ((uint32_t)colors_rgb[3 * e + 1] << 8) | ((uint32_t)colors_rgb[3 * e + 2] << 16);
-    HIP_TRY(h, hipMemcpyAsync(ws + L.strokes, strokes, (size_t)T * n_edges * sizeof(rib_stroke), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(ws + L.colors, packed.data(), n_edges * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  // The four tables sit at the head of the workspace in one contiguous range [0, L.canvas): they are assembled in a page-locked
+  // staging slot and go over in ONE asynchronous copy.  (Rounds 1-3 copied from the caller's pageable arrays and then
+  // synchronised the stream so that the arrays could be reused: where the upload stream shares a hardware queue with the
+  // stream a chain runs on, that wait was the previous segment's whole chain - 60 ms per call, profiles/r04_prof_driver.txt.)
+  {
+    rib_handle::RasterStage& rs = h->raster_stage[h->raster_next];
+    h->raster_next ^= 1;
+    if (rs.done) HIP_TRY(h, hipEventSynchronize(rs.done));      // the copy out of this slot two calls ago
+    else HIP_TRY(h, hipEventCreateWithFlags(&rs.done, hipEventDisableTiming));
+    if (rs.bytes < L.canvas) {
+      if (rs.host) (void)hipHostFree(rs.host);
+      rs.host = nullptr; rs.bytes = 0;
+      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&rs.host), L.canvas, hipHostMallocDefault));
+      rs.bytes = L.canvas;
+    }
+    memset(rs.host, 0, L.canvas);
+    if (n_edges > 0) {
+      memcpy(rs.host + L.strokes, strokes, (size_t)T * n_edges * sizeof(rib_stroke));
+      uint32_t* packed = reinterpret_cast<uint32_t*>(rs.host + L.colors);
+      for (int e = 0; e < n_edges; ++e)
+        packed[e] = (uint32_t)colors_rgb[3 * e] | ((uint32_t)colors_rgb[3 * e + 1] << 8) | ((uint32_t)colors_rgb[3 * e + 2] << 16);
+    }
+    if (n_maps > 0) {
+      memcpy(rs.host + L.peaks, peaks, (size_t)T * n_maps * 2 * sizeof(int32_t));
+      memcpy(rs.host + L.weights, weights, (size_t)(radius + 1) * sizeof(double));
+    }
+    HIP_TRY(h, hipMemcpyAsync(ws, rs.host, L.canvas, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipEventRecord(rs.done, st));
   }
-  if (n_maps > 0) {
-    HIP_TRY(h, hipMemcpyAsync(ws + L.peaks, peaks, (size_t)T * n_maps * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(ws + L.weights, weights, (size_t)(radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
-  }
-  HIP_TRY(h, hipStreamSynchronize(st));        // the caller's (pageable) tables may be reused on return; they are KBs
   if (n_maps > 0) {
     HeatParams hp;
     hp.peaks = reinterpret_cast<const int32_t*>(ws + L.peaks); hp.w = reinterpret_cast<const double*>(ws + L.weights);

@@ -18,9 +18,11 @@ Differences from the reference, none of which change a pixel:
     the 32x32 / 64x64 maps; a chain is cut into time chunks of `chunk` steps whose first `prev`
     is the previous chunk's last fused frame on the device, so that decode, GPU work and PNG encode of
     different chunks overlap (a unit of the pipeline is `chunk` x B frames);
-  * file decode / encode runs on a thread pool, the quantised frames of a chunk come back in
-    one pinned device-to-host copy, and the three phases are pipelined over chunks (SURVEY 8 row
-    f-1: at hundreds of frames/s the per-frame .cpu() + PNG encode of evaluator.py:260-266 is the wall);
+  * file decode / json -> rasteriser tables / PNG encode run in a pool of worker PROCESSES (io_worker.py) that read
+    and write the frames in page-locked shared memory: the decoded frames of a chunk go up and its quantised
+    frames come back in one asynchronous copy each, and the three phases are pipelined over chunks (SURVEY 8 row
+    f-1: at hundreds of frames/s the per-frame .cpu() + PNG encode of evaluator.py:260-266 is the wall - and at PIL's
+    default zlib level, the bytes the reference writes, it still is: 54 ms of CPU per 512x512 frame);
   * multi-GPU: the independent units (the segments between key frames, evaluator.py:240-244, over all clips,
     :169-171) are dealt round-robin to the ranks of the process group (distributed.shard_units); every rank
     decodes, renders and writes only its own frames, with no communication after the weight broadcast.
@@ -59,25 +61,149 @@ def split_segments(seq_len: int, sample_rate: int):
 _PROC_POOLS = {}
 
 
+class _ProcessPool:
+    """n worker processes with a concurrent.futures face (submit -> Future).  forkserver: the workers are forked from a clean
+    server process that never saw the GPU (a plain fork of a process with an initialised HIP runtime is not safe), with this
+    package's file-side module preloaded so that a fork is cheap.  multiprocessing would also re-run the parent's __main__
+    script in every worker ("__mp_main__": for a driver script that means importing torch 32 times, which is what made the first
+    version of this pool 3x slower than threads); the workers only ever run io_worker functions, so __main__ is hidden
+    while they are started - multiprocessing.Pool starts all of them in its constructor."""
+
+    def __init__(self, n):
+        import multiprocessing as mp
+        import sys
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["render_in_between_amd.io_worker", "PIL.Image", "PIL.PngImagePlugin", "scipy.optimize"])
+        main = sys.modules.get("__main__")
+        saved = {k: getattr(main, k) for k in ("__file__", "__spec__") if hasattr(main, k)}
+        # one BLAS / OpenMP thread per worker (io_worker.warm says why); the variables are read when the forkserver imports numpy
+        threads_env = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+        try:
+            if hasattr(main, "__file__"):
+                del main.__file__
+            if main is not None:
+                main.__spec__ = None
+            for k in threads_env:
+                os.environ[k] = "1"
+            self._pool = ctx.Pool(n, initializer=io_worker.warm)
+        finally:
+            for k, v in saved.items():
+                setattr(main, k, v)
+            for k, v in threads_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self.n = n
+
+    def submit(self, fn, *args):
+        from concurrent.futures import Future
+        fut = Future()
+        fut.set_running_or_notify_cancel()
+        self._pool.apply_async(fn, args, callback=fut.set_result, error_callback=fut.set_exception)
+        return fut
+
+    def shutdown(self):
+        self._pool.terminate()
+
+
+class _ShmBlock:
+    """A block of POSIX shared memory that worker processes open by name (io_worker._attach) and that is also page-locked
+    for the GPU (hipHostRegister), so that the upload of decoded frames and the download of quantised frames are asynchronous
+    copies straight out of / into the memory the workers write / read.  `t`: the block as a flat uint8 tensor."""
+
+    def __init__(self, nbytes):
+        from multiprocessing import shared_memory
+        self.nbytes = int(nbytes)
+        self.shm = shared_memory.SharedMemory(create=True, size=self.nbytes)
+        self.name = self.shm.name
+        self.t = torch.from_numpy(np.ndarray((self.nbytes,), np.uint8, buffer=self.shm.buf))
+        self.pinned = False
+        if torch.cuda.is_available():
+            try:
+                self.pinned = int(torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), self.nbytes, 0)) == 0
+            except Exception:                                   # noqa: BLE001 (not pinned: the copies are synchronous, still correct)
+                self.pinned = False
+
+    def close(self):
+        if self.shm is None:
+            return
+        if self.pinned:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self.t.data_ptr())
+            except Exception:                                   # noqa: BLE001
+                pass
+        self.t = None
+        try:
+            self.shm.close()
+            self.shm.unlink()
+        except Exception:                                       # noqa: BLE001
+            pass
+        self.shm = None
+
+
+_SHM_FREE = {}          # nbytes -> [idle _ShmBlock]: blocks are reused across units and calls (creating + page-locking one costs ms)
+_SHM_ALL = []
+
+
+def _shm_get(nbytes):
+    free = _SHM_FREE.get(nbytes)
+    if free:
+        return free.pop()
+    if not _SHM_ALL:
+        import atexit
+        atexit.register(_shm_close_all)
+    blk = _ShmBlock(nbytes)
+    _SHM_ALL.append(blk)
+    return blk
+
+
+def _shm_put(blk):
+    _SHM_FREE.setdefault(blk.nbytes, []).append(blk)
+
+
+def _shm_close_all():
+    for blk in _SHM_ALL:
+        blk.close()
+    _SHM_ALL.clear()
+    _SHM_FREE.clear()
+
+
 def _process_pool(n):
-    """One pool of n worker processes per size for the whole process (Evaluators come and go; 32 interpreters should not).
-    forkserver: the workers are forked from a clean server process that never saw the GPU (a plain fork of a process with
-    an initialised HIP runtime is not safe), with this package's file-side module preloaded so that a fork is cheap."""
+    """One pool of n worker processes per size for the whole process (Evaluators come and go; 32 interpreters should not)."""
     pool = _PROC_POOLS.get(n)
     if pool is None:
         import atexit
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
-        ctx = mp.get_context("forkserver")
-        ctx.set_forkserver_preload(["render_in_between_amd.io_worker", "PIL.Image", "PIL.PngImagePlugin", "scipy.optimize"])
-        pool = _PROC_POOLS[n] = ProcessPoolExecutor(n, mp_context=ctx)
-        list(pool.map(_warm, range(n)))          # start them all now, not under the first clip
-        atexit.register(pool.shutdown, wait=False, cancel_futures=True)
+        pool = _PROC_POOLS[n] = _ProcessPool(n)
+        atexit.register(pool.shutdown)
     return pool
 
 
-def _warm(_):
-    return io_worker.warm()
+def cpu_budget():
+    """CPUs this process can actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of the pool shows 256
+    CPUs and grants 16 cores' worth of time: more file workers than that only take turns - profiles/r04_encode_probe.txt)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", ):
+        try:
+            with open(path) as f:
+                quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:                                                        # cgroup v1
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0 and period > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _list(d, exts):
@@ -85,7 +211,7 @@ def _list(d, exts):
 
 
 class Evaluator:
-    def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=8, io_threads=None,
+    def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=4, io_threads=None,
                  io_mode="process"):
         """batch: independent segments of equal length rendered as ONE chain of that batch size (None: by frame size,
         `default_batch`; 1: every segment on its own, the round-1..3 behaviour).  Per-sample arithmetic does not depend
@@ -95,7 +221,7 @@ class Evaluator:
         lanes: independent chains kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (the frames inside a segment stay strictly sequential).
         io_threads: decode / encode workers (None: the CPUs this process may run on, divided by the ranks of the job
-        sharing the host, at most 48).
+        sharing the host and by the cgroup's CPU quota (cpu_budget), minus one for the launch thread, at most 48).
         io_mode: "process" (default) runs the file-side work of the native pipeline - decode, json -> rasteriser tables,
         PNG encode - in a pool of worker processes shared by all Evaluators of this process (io_worker.py), so that it
         cannot hold the interpreter lock of the thread that enqueues the GPU work; "thread": a thread pool (rounds 1-3).
@@ -118,10 +244,7 @@ class Evaluator:
         self.png_compress_level = png_compress_level
         self.batch = None if batch is None else max(1, int(batch))
         self.chunk = max(0, int(chunk))
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncpu = os.cpu_count() or 1
+        ncpu = cpu_budget()
         # N ranks on one host share its cores: LOCAL_WORLD_SIZE (torchrun) or WORLD_SIZE ranks each take their part, and one
         # core per rank stays with the launch thread (5 k launches per 31-frame segment); more workers than cores only slow it
         ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
@@ -290,7 +413,7 @@ class Evaluator:
             # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of
             # the pipeline with one pinned staging buffer that the decode workers fill in place (no stack on the launch
             # thread, and the upload from pinned memory is asynchronous)
-            units, stage, slot = [], {}, {}
+            units, stage, slot, stage_blk = [], {}, {}, {}
             if native:
                 B_ = self.batch or self.default_batch()
                 for gi, members in enumerate(self.group_segments(segs, B_)):
@@ -300,7 +423,11 @@ class Evaluator:
                         c1 = min(T, c0 + step)
                         ui = len(units)
                         units.append((gi, members, c0, c1))
-                        stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
+                        if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
+                            stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
+                            stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
+                        else:
+                            stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
                         for b, si in enumerate(members):
                             for t in range(c0, c1):
                                 slot[segs[si][1][t]] = (ui, t - c0, b)
@@ -321,24 +448,23 @@ class Evaluator:
                     pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
                 return dain, gt, pose
 
-            def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
+            def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot, stage_blk=stage_blk):
                 """The same pre-load in a worker process; its result is unpacked (the DAIN frame copied into its pinned staging
                 slot, arrays wrapped as tensors) by the pool's result thread as soon as it arrives."""
                 from concurrent.futures import Future
                 ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
-                src = procs.submit(io_worker.load_frame, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0, gpu_labels,
-                                   self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
+                name, off = "", -1
+                if i in slot:                               # the worker decodes straight into the unit's shared staging block
+                    ui, t, b = slot[i]
+                    name, off = stage_blk[ui].name, (t * stage[ui].shape[1] + b) * self.height * self.width * 3
+                src = procs.submit(io_worker.load_frame_shm, name, off, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0,
+                                   gpu_labels, self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
                 out = Future()
 
                 def unpack(f):
                     try:
-                        dain, gt, pose = f.result()
-                        dain = torch.from_numpy(dain)
-                        if i in slot:
-                            ui, t, b = slot[i]
-                            stage[ui][t, b].copy_(dain)
-                            dain = None
-                        out.set_result((dain, torch.from_numpy(gt) if gt is not None else None, pose))
+                        _, gt, pose = f.result()
+                        out.set_result((None, torch.from_numpy(io_worker.normalised_chw(gt)) if gt is not None else None, pose))
                     except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
                         out.set_exception(e)
                 src.add_done_callback(unpack)
@@ -397,7 +523,8 @@ class Evaluator:
                     fz = g.chain(gtd if c0 == 0 else prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
                     prev_of[gi] = fz[-1]
                     q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
-                    pinned = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                    out_blk = _shm_get(q.numel()) if procs is not None else None       # shared with the encode workers, page-locked
+                    pinned = out_blk.t.view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
                     pinned.copy_(q, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(st)
@@ -405,13 +532,28 @@ class Evaluator:
                 tm["generate"] += time.perf_counter() - t2
                 out_frames = [segs[si][1][t] for t in range(c0, c1) for si in members]
 
-                def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd)):
-                    done.synchronize()
+                t_enq = time.perf_counter() - t_wall
+
+                def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd), in_blk=stage_blk.get(ui),
+                           out_blk=out_blk, t_enq=t_enq, t_loaded=t1 - t_wall):
+                    done.synchronize()                      # the chain, the quantiser and the download are done: so is the upload
+                    # per unit: inputs decoded, launches enqueued, results on the host, files written (seconds since the call began)
+                    mark = [round(t_loaded, 4), round(t_enq, 4), round(time.perf_counter() - t_wall, 4)]
+                    tm.setdefault("timeline", []).append(mark)
+                    if in_blk is not None:
+                        _shm_put(in_blk)
+                    if out_blk is not None:
+                        fsz = self.height * self.width * 3
+                        fs = [procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, self.height, self.width, names[out_frames[j]], level)
+                              for j in range(len(out_frames))]
+                        res = [f.result() for f in fs]
+                        _shm_put(out_blk)
+                        mark.append(round(time.perf_counter() - t_wall, 4))
+                        return res
                     qn = pinned.numpy()
-                    if procs is not None:
-                        fs = [procs.submit(io_worker.save_png, qn[j], names[out_frames[j]], level) for j in range(len(out_frames))]
-                        return [f.result() for f in fs]
-                    return list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
+                    res = list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
+                    mark.append(round(time.perf_counter() - t_wall, 4))
+                    return res
                 seg_fut = finishers.submit(finish)
                 for j, i in enumerate(out_frames):
                     futs[i] = (seg_fut, j)

@@ -69,8 +69,56 @@ def save_png(u8, name, compress_level=None):
     return name
 
 
+# ---- shared-memory variants: the pixel payloads never go through a pipe -------------------------------------------------------
+# A frame is 0.2-0.8 MB.  Pickled through multiprocessing's single result pipe it takes a dozen 64 KB reads in the parent's
+# result thread, each of which has to win the interpreter lock back from the thread that enqueues the GPU work: the first
+# process pool of this driver spent 2-4 s per clip there (profiles/r04_driver.jsonl).  So the parent hands out names of
+# shared-memory blocks (Evaluator._ShmBlock: also page-locked for the GPU copies); workers decode INTO and encode OUT OF them,
+# and only file names, offsets and the small rasteriser tables travel.
+_SHM = {}
+
+
+def _attach(name):
+    shm = _SHM.get(name)
+    if shm is None:
+        from multiprocessing import shared_memory
+        if len(_SHM) > 64:
+            for old in _SHM.values():
+                old.close()
+            _SHM.clear()
+        # (attaching registers the name with the resource tracker again; the workers share the parent's tracker process, where
+        # that is a no-op on a set - the parent, which created the block, unlinks and unregisters it)
+        shm = _SHM[name] = shared_memory.SharedMemory(name=name)
+    return shm
+
+
+def load_frame_shm(shm_name, offset, dain_path, ref_img_path, pose_path, is_key, want_tables, width, height, resize, thres1, thres2):
+    """load_frame with the DAIN frame written to bytes [offset, offset + H*W*3) of a shared block (offset < 0: not wanted,
+    the frame is a key frame that passes through); returns (None, key frame uint8 HWC or None, tables)."""
+    if offset >= 0:
+        dain, _ = decode_resized_u8(dain_path, width, height, resize)
+        dst = np.ndarray((height, width, 3), np.uint8, buffer=_attach(shm_name).buf, offset=offset)
+        dst[...] = dain
+    gt = decode_resized_u8(ref_img_path, width, height, resize)[0] if is_key else None
+    lm, conf = scaled_pose(pose_path, image_size(ref_img_path), width, height)
+    pose = rasterise.frame_tables(lm, conf, height, width, thres1, thres2) if want_tables else (lm, conf)
+    return None, gt, pose
+
+
+def save_png_shm(shm_name, offset, height, width, name, compress_level=None):
+    """save_png of the uint8 HWC frame at bytes [offset, ..) of a shared block."""
+    return save_png(np.ndarray((height, width, 3), np.uint8, buffer=_attach(shm_name).buf, offset=offset), name, compress_level)
+
+
 def warm():
-    """First task of a fresh worker: pull in PIL's codecs and scipy's curve_fit before real work arrives."""
+    """Initialiser of a fresh worker process.  (1) One BLAS / OpenMP thread: numpy's OpenBLAS starts one thread per core of the
+    host in EVERY process and they spin between calls - 32 workers x 256 threads on the GPU boxes made a 10 ms decode take 500 ms
+    (tools/probes/io_pool_probe.py).  (2) Pull in PIL's codecs and scipy's curve_fit before real work arrives."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:                                           # noqa: BLE001 (no threadpoolctl: the environment variables below apply)
+        pass
     from PIL import Image, PngImagePlugin, JpegImagePlugin      # noqa: F401
     from scipy.optimize import curve_fit                        # noqa: F401
     return True

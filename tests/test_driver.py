@@ -295,8 +295,23 @@ def test_io_worker_processes_return_what_the_threads_compute(tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(got[2], want[2]))
     E = ev.Evaluator(rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48))
     assert torch.equal(E.load_image(key)[0], torch.from_numpy(want[1]))
+    # the shared-memory variants the pipeline uses: pixels go through a named block, never through the result pipe
+    blk = ev._shm_get(2 * 32 * 48 * 3)
+    try:
+        off = 32 * 48 * 3
+        got = pool.submit(io_worker.load_frame_shm, blk.name, off, *args).result()
+        assert got[0] is None and np.array_equal(blk.t.numpy()[off:].reshape(32, 48, 3), want[0])
+        assert np.array_equal(io_worker.normalised_chw(got[1]), want[1])
+        assert all(np.array_equal(a, b) for a, b in zip(got[2], want[2]))
+        shm_png = os.path.join(root, "s.png")
+        assert pool.submit(io_worker.save_png_shm, blk.name, off, 32, 48, shm_png, None).result() == shm_png
+    finally:
+        ev._shm_put(blk)
+    assert ev._shm_get(2 * 32 * 48 * 3) is blk              # blocks are reused by size
+    ev._shm_put(blk)
     out = os.path.join(root, "w.png")
     assert pool.submit(io_worker.save_png, want[0], out, None).result() == out
+    assert open(out, "rb").read() == open(shm_png, "rb").read()
     ref = os.path.join(root, "r.png")
     Image.fromarray(want[0]).save(ref)
     assert open(out, "rb").read() == open(ref, "rb").read()

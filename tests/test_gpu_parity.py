@@ -297,7 +297,7 @@ def test_driver_batched_and_chunked_segments(tmp_path):
     base = ev.Evaluator(cfg, lanes=1, batch=1, chunk=0).evaluate_from_folder(G, *dirs, os.path.join(root, "a"))
     chunked = ev.Evaluator(cfg, lanes=1, batch=1, chunk=2).evaluate_from_folder(G, *dirs, os.path.join(root, "b"))
     batched = ev.Evaluator(cfg, lanes=2, batch=4, chunk=2).evaluate_from_folder(G, *dirs, os.path.join(root, "c"))
-    default = ev.Evaluator(cfg).evaluate_from_folder(G, *dirs, os.path.join(root, "d"))      # batch 8 at this size, chunk 8
+    default = ev.Evaluator(cfg).evaluate_from_folder(G, *dirs, os.path.join(root, "d"))      # batch 8 at this size, chunk 4, worker processes
     assert len(base) == len(chunked) == len(batched) == len(default) == n == 21
     for fa, fb, fc, fd in zip(base, chunked, batched, default):
         a = np.asarray(Image.open(fa)).astype(int)
@@ -953,7 +953,7 @@ def test_dma_staged_kernel_variants_agree_with_the_register_staged_ones():
     for i in range(lib.rib_num_variants()):
         if lib.rib_variant_info(i, g12) == 0 and g12[11] in (100, 109):      # 100: one slice per barrier; 109: a whole chunk (tile + nine slices) per barrier
             kinds.setdefault(g12[11], []).append(i)
-    assert len(kinds[100]) >= 20 and len(kinds[109]) >= 8
+    assert len(kinds[100]) >= 8 and len(kinds[109]) >= 3      # (round 4 pruned the table to the entries some launch plan uses: 10 + 4)
     for (B, H, W), prefer in (((1, 128, 128), 109), ((2, 48, 80), 100), ((1, 256, 256), 109), ((1, 128, 128), 100)):
         dma_idx = kinds[prefer] + kinds[209 - prefer]
         label, fake, prev = synth.make_inputs(spec, B, H, W, 31)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rate of the folder driver (json + PNG in, PNG out) on a synthetic clip.
 
-    python tools/driver_bench.py [--size 512 | --height 320 --width 480] [--keys 5] [--rate 32] [--lanes 2] [--batch B] [--chunk 8]
+    python tools/driver_bench.py [--size 512 | --height 320 --width 480] [--keys 5] [--rate 32] [--lanes 2] [--batch B] [--chunk 4]
 
 Writes a clip in the reference's directory layout (inputs/ DAIN/ Predict_motion/), runs
 Evaluator.evaluate_from_folder twice (the first run also builds launch plans) and prints the
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="segments per chain (0: the Evaluator's default for the frame size)")
-    ap.add_argument("--chunk", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=4)
     ap.add_argument("--io-threads", type=int, default=0)
     ap.add_argument("--compress", type=int, default=-1, help="PNG compress level (-1: PIL's default, 6, as the reference)")
     ap.add_argument("--io-mode", default="process", choices=("process", "thread"))
@@ -79,9 +79,10 @@ def main():
     wall = sorted(walls[1:])[len(walls[1:]) // 2]
     print(json.dumps({"height": H, "width": W, "dtype": a.dtype, "frames": n, "generated": gen, "lanes": a.lanes,
                       "batch": a.batch or E.default_batch(), "chunk": a.chunk, "io_threads": E.io_threads, "io_mode": a.io_mode,
-                      "cpus": len(os.sched_getaffinity(0)), "png_compress_level": a.compress,
+                      "cpus": len(os.sched_getaffinity(0)), "cpu_budget": ev.cpu_budget(), "png_compress_level": a.compress,
                       "wall_s": wall, "wall_s_runs": [round(w, 4) for w in walls[1:]], "frames_per_s_end_to_end": n / wall,
-                      "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units")},
+                      "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units", "timeline")},
+                      "unit_timeline_s [decoded, enqueued, on host, written]": tm.get("timeline"),
                       "pipeline_units_last_run": tm.get("units")}))
 
 

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Regenerate the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r03
+#   bash tools/refresh_profiles.sh r04
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# which build made these files: bench.py quotes the committed rocprofv3 / PMC figures only beside the same build's stamp
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from render_in_between_amd import _native; b = _native.build_info(); print(b['stamp'], b['raw'])" > $OUT/${TAG}_build_stamp.txt
 echo "[refresh] bench (default command)"; python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[refresh] rocprofv3 --stats of the bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_prof.log 2>&1
@@ -15,6 +17,12 @@ cp $OUT/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 echo "[refresh] per-op table"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_prof_ops.log 2>&1
 python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops --json $OUT/${TAG}_prof_ops_512.json > $OUT/${TAG}_prof_ops_512.txt
+echo "[refresh] per-op table at the reference's default working resolution (320x480) and of the batch-4 frame"
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops_320 -- python3 $ROOT/tools/prof_ops.py --run --height 320 --width 480 > $OUT/${TAG}_prof_ops_320.log 2>&1
+python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_320 --height 320 --width 480 > $OUT/${TAG}_prof_ops_320x480.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops_b4 -- python3 $ROOT/tools/prof_ops.py --run --batch 4 > $OUT/${TAG}_prof_ops_b4.log 2>&1
+python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_b4 --batch 4 > $OUT/${TAG}_prof_ops_512_b4.txt
+rm -rf $OUT/prof_ops_320 $OUT/prof_ops_b4
 echo "[refresh] PMC passes (separate runs, kernel trace only)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_w.log 2>&1
@@ -31,7 +39,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_I
 done
 echo "[refresh] other shapes and modes"
 rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
-for flags in "--mode chain --frames 32" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype f16" "--dtype f16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
+for flags in "--height 320 --width 480" "--height 320 --width 480 --no-tuning" "--height 320 --width 480 --dtype bf16" "--height 320 --width 480 --dtype bf16 --no-tuning" "--height 320 --width 480 --mode chain --frames 16 --batch 8" "--height 320 --width 480 --dtype bf16 --mode chain --frames 16 --batch 8" "--mode chain --frames 32" "--mode chain --frames 32 --batch 4" "--mode chain --frames 32 --batch 8" "--mode clips --frames 32" "--mode clips --frames 32 --graph" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype bf16 --mode chain --frames 32 --batch 4" "--dtype f16" "--dtype f16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
@@ -48,8 +56,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/warp_f -- 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/warp_w -- python3 $ROOT/tools/warp_bench.py --run > /dev/null 2>&1
 python3 $ROOT/tools/warp_bench.py --report $OUT/warp_f $OUT/warp_w --out $OUT/${TAG}_warp_pmc.json > $OUT/${TAG}_warp_pmc.log 2>&1
 rm -rf $OUT/warp_f $OUT/warp_w
-echo "[refresh] LDS-DMA probe"
-[ -x $ROOT/tools/probes/bin/ldsdma_probe ] && timeout -k 10 120 $ROOT/tools/probes/bin/ldsdma_probe > $OUT/${TAG}_ldsdma_probe.txt 2>&1
+echo "[refresh] folder driver end to end (files in, files out)"
+rm -f $OUT/${TAG}_driver.jsonl
+for flags in "--size 512 --keys 5 --rate 32" "--size 512 --keys 3 --rate 32" "--size 512 --keys 5 --rate 32 --dtype bf16" "--size 512 --keys 5 --rate 32 --io-mode thread --batch 1 --lanes 3 --chunk 0 --io-threads 16" "--size 512 --keys 5 --rate 32 --compress 1" "--height 320 --width 480 --keys 9 --rate 16" "--height 320 --width 480 --keys 5 --rate 16" "--height 320 --width 480 --keys 9 --rate 16 --dtype bf16"; do
+  echo "## $flags" >> $OUT/${TAG}_driver.jsonl
+  timeout -k 10 300 python3 $ROOT/tools/driver_bench.py $flags >> $OUT/${TAG}_driver.jsonl 2>> $OUT/${TAG}_driver.err
+done
 echo "[refresh] motion transformer"
 python3 $ROOT/tools/motion_bench.py --out $OUT/${TAG}_motion_bench.json > $OUT/${TAG}_motion_bench.log 2>&1
 rm -rf $OUT/prof_bench $OUT/prof_ops $OUT/pmc_f $OUT/pmc_w $OUT/prof_bf16
