@@ -45,8 +45,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)      # ~1 s of timed device work at 512x512: long enough for an outside GPU-busy sampler to see it
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=512, help="square frames: shorthand for --height S --width S")
     ap.add_argument("--height", type=int, default=0, help="frame height (with --width), e.g. the reference's default working "
                                                           "resolution --height 320 --width 480 (PGNR/configs/HSM.yaml:192-193)")
