@@ -59,6 +59,9 @@ def split_segments(seq_len: int, sample_rate: int):
 
 
 _PROC_POOLS = {}
+# A task whose worker process died never completes under multiprocessing.Pool (the pool replaces the worker, not the task):
+# every wait on file-side work is bounded, so that a lost task ends the call with an error instead of hanging it.
+IO_TIMEOUT_S = 300.0
 
 
 class _ProcessPool:
@@ -376,7 +379,7 @@ class Evaluator:
 
         def save_q(q, name):                                  # uint8 HWC -> file, here or in a worker process
             if procs is not None:
-                return procs.submit(io_worker.save_png, q, name, level).result()
+                return procs.submit(io_worker.save_png, q, name, level).result(timeout=IO_TIMEOUT_S)
             return io_worker.save_png(q, name, level)
 
         def save_host(x, name):                               # utils/utils.py:129-142 on the host
@@ -485,13 +488,13 @@ class Evaluator:
             lanes = self._lanes(model, ngroups) if native else None
             futs = {}
             for k in keys:                                                         # key frames pass through (evaluator.py:240-244)
-                futs[k] = finishers.submit(lambda k=k, loads=loads, names=names: save_host(loads[k].result()[1].unsqueeze(0), names[k]))
+                futs[k] = finishers.submit(lambda k=k, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
             prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
             for ui, (gi, members, c0, c1) in enumerate(units):
                 t0 = time.perf_counter()
                 Tc, Bc = c1 - c0, len(members)
-                got = [loads[segs[si][1][t]].result() for t in range(c0, c1) for si in members]      # (t, b) order
-                gt = torch.stack([loads[segs[si][0]].result()[1] for si in members]) if c0 == 0 else None
+                got = [loads[segs[si][1][t]].result(timeout=IO_TIMEOUT_S) for t in range(c0, c1) for si in members]      # (t, b) order
+                gt = torch.stack([loads[segs[si][0]].result(timeout=IO_TIMEOUT_S)[1] for si in members]) if c0 == 0 else None
                 t1 = time.perf_counter()
                 tm["load"] += t1 - t0
                 poses = [g_[2] for g_ in got]
@@ -546,7 +549,7 @@ class Evaluator:
                         fsz = self.height * self.width * 3
                         fs = [procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, self.height, self.width, names[out_frames[j]], level)
                               for j in range(len(out_frames))]
-                        res = [f.result() for f in fs]
+                        res = [f.result(timeout=IO_TIMEOUT_S) for f in fs]
                         _shm_put(out_blk)
                         mark.append(round(time.perf_counter() - t_wall, 4))
                         return res
