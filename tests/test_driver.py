@@ -315,3 +315,10 @@ def test_io_worker_processes_return_what_the_threads_compute(tmp_path):
     ref = os.path.join(root, "r.png")
     Image.fromarray(want[0]).save(ref)
     assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+def test_cpu_budget_is_positive_and_bounded_by_the_affinity_mask():
+    n = ev.cpu_budget()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    E = ev.Evaluator(rib.AttrDict(gen=rib.hsm_gen_config(**MID_CFG), model_height=32, model_width=48))
+    assert 1 <= E.io_threads <= max(1, n - 1) or n == 1

@@ -631,6 +631,40 @@ def test_chain_with_batched_label_work_matches_the_per_frame_chain(monkeypatch):
         assert float((f1[t].cpu() - prev).abs().max()) < TOL, t
 
 
+def test_kernel_time_profiling_counts_every_launch():
+    """bench.py's roofline: rib_profile_begin_kernels binds a (start, stop) event pair to every dispatch.  Every launch of the
+    plan is counted in its class, the kernels' own times are positive and add up to roughly the forward's wall time (they
+    exclude the gaps between dependent launches and include nothing else), the interval-event mode still works, and
+    profiling leaves the frame untouched."""
+    import time
+    spec, sd, G = build("full", 0)
+    B, H, W = 1, 256, 256
+    label, fake, prev = [t.cuda() for t in synth.make_inputs(spec, B, H, W, 5)]
+    want = [t.clone() for t in G(label, None, fake, prev)]
+    n = G.num_launches(B, H, W)
+    for _ in range(3):
+        G(label, None, fake, prev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        G(label, None, fake, prev)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / 10 * 1e3
+    for kernels in (True, False):
+        G.profile_begin(kernels=kernels)
+        for _ in range(4):
+            got = G(label, None, fake, prev)
+        prof = G.profile_collect()
+        assert sum(v["launches"] for v in prof.values()) == 4 * n, (kernels, prof)
+        assert prof["igemm"]["launches"] > 0 and all(v["ms"] >= 0 for v in prof.values())
+        per_fwd = sum(v["ms"] for v in prof.values()) / 4
+        assert 0.5 * wall_ms < per_fwd < (1.6 if kernels else 3.0) * wall_ms, (kernels, per_fwd, wall_ms)
+        assert all(torch.equal(a, b) for a, b in zip(want, got))
+    got = G(label, None, fake, prev)              # profiling is off again
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
 def test_chain_graph_replay_is_bit_identical():
     """rib_chain as ONE HIP graph launch.  The first call with a given shape and set of tensors captures
     the segment's launches, later calls replay the graph: same kernels, parameters and order, so the frames equal the
