@@ -77,7 +77,7 @@ def main(opts):
         torch.cuda.set_device(device)
         ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"), device)
     net_G = load_generator(config, device, rank, world, opts.dtype)
-    evaluator = Evaluator(config)
+    evaluator = Evaluator(config, batch=opts.batch or None)
     train_dir = os.path.join(opts.input_dir, "inputs")
     dain_dir = os.path.join(opts.input_dir, "DAIN")
     pose_dir = os.path.join(opts.input_dir, "Predict_motion")
@@ -99,4 +99,7 @@ if __name__ == "__main__":
                         help="f32: the reference's arithmetic (default); bf16 / f16: 16-bit storage, ~2x the frame rate, ~1e-2 / ~1e-3 mean deviation "
                              "(not in the reference: it is fp32 only)")
     parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")
+    parser.add_argument("--batch", type=int, default=0,
+                        help="independent segments rendered as one chain of that batch size (0: by frame size - 8 at 320x480, 4 at 512x512; "
+                             "1: one chain per segment, which also makes an N-rank run byte-identical to a 1-rank run)")
     main(parser.parse_args())
