@@ -62,6 +62,11 @@ _PROC_POOLS = {}
 # A task whose worker process died never completes under multiprocessing.Pool (the pool replaces the worker, not the task):
 # every wait on file-side work is bounded, so that a lost task ends the call with an error instead of hanging it.
 IO_TIMEOUT_S = 300.0
+# Windows of the pipeline, in units (a unit = chunk x B frames): decode runs at most DECODE_AHEAD units ahead of the unit being
+# enqueued, and at most MAX_UNITS_IN_FLIGHT units are enqueued but not yet written - host and device memory are bounded by the
+# windows, not by the length of the clip.
+DECODE_AHEAD = int(os.environ.get("RIB_DECODE_AHEAD", "6"))
+MAX_UNITS_IN_FLIGHT = int(os.environ.get("RIB_MAX_UNITS_IN_FLIGHT", "10"))
 
 
 class _ProcessPool:
@@ -261,6 +266,23 @@ class Evaluator:
         self.skeleton_thres = getattr(cfg, "skeleton_thres", 0.001)
         self.foot_thres = getattr(cfg, "foot_thres", 0.001)
 
+    def _shm_fits(self):
+        """Is there room in /dev/shm for the pipeline's windows of shared staging blocks?  (A container may mount 64 MB there,
+        and a write beyond it is a bus error, not an exception: the file-side work then stays on threads, with a warning.)"""
+        unit = max(1, self.chunk) * (self.batch or self.default_batch()) * self.height * self.width * 3
+        need = (DECODE_AHEAD + MAX_UNITS_IN_FLIGHT + 4) * unit
+        try:
+            st = os.statvfs("/dev/shm")
+            free = st.f_bavail * st.f_frsize
+        except OSError:
+            free = 0
+        if free < need:
+            import warnings
+            warnings.warn("Evaluator: /dev/shm has %.0f MB free, the shared staging blocks of the worker processes need %.0f MB: "
+                          "falling back to io_mode='thread'" % (free / 1e6, need / 1e6))
+            return False
+        return True
+
     def default_batch(self):
         """Segments per chain when the caller did not say: enough samples to fill 256 CUs on the deep (1/16-resolution,
         512-channel) layers without growing the working set past the MALL - 8 at the reference's 320x480, 4 at 512x512
@@ -374,7 +396,7 @@ class Evaluator:
                     sizes[path] = im.size
             return sizes[path]
 
-        procs = _process_pool(self.io_threads) if (native and self.io_mode == "process") else None
+        procs = _process_pool(self.io_threads) if (native and self.io_mode == "process" and self._shm_fits()) else None
         level = self.png_compress_level
 
         def save_q(q, name):                                  # uint8 HWC -> file, here or in a worker process
@@ -423,17 +445,7 @@ class Evaluator:
                     T = len(segs[members[0]][1])
                     step = self.chunk if self.chunk > 0 else T
                     for c0 in range(0, T, step):
-                        c1 = min(T, c0 + step)
-                        ui = len(units)
-                        units.append((gi, members, c0, c1))
-                        if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
-                            stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
-                            stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
-                        else:
-                            stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
-                        for b, si in enumerate(members):
-                            for t in range(c0, c1):
-                                slot[segs[si][1][t]] = (ui, t - c0, b)
+                        units.append((gi, members, c0, min(T, c0 + step)))
 
             def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
                 dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
@@ -473,24 +485,44 @@ class Evaluator:
                 src.add_done_callback(unpack)
                 return out
             keys = my_keys
-            if native:
-                # decode in the order the launch thread will ask for the frames: unit by unit, the unit's key frames first
-                order, seen = [], set()
-                for gi, members, c0, c1 in units:
-                    want = [segs[si][0] for si in members] if c0 == 0 else []
-                    want += [segs[si][1][t] for t in range(c0, c1) for si in members]
-                    order += [i for i in want if not (i in seen or seen.add(i))]
-                order += [k for k in keys if k not in seen]
-            else:
-                order = sorted(set(my_keys) | {i for _, frames in segs for i in frames})
-            loads = {i: (load_in_worker(i) if procs is not None else pool.submit(load, i)) for i in order}      # FIFO
+            loads, futs, opened = {}, {}, [0]
+
+            def submit_load(i):
+                if i not in loads:
+                    loads[i] = load_in_worker(i) if procs is not None else pool.submit(load, i)
+                    if i in keys and i not in futs:                                # key frames pass through (evaluator.py:240-244)
+                        futs[i] = finishers.submit(lambda k=i, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
+
+            def open_units(upto):
+                """Staging block, slots and decode tasks of the units up to index `upto`: the launch thread keeps DECODE_AHEAD units
+                open beyond the one it is enqueueing, so that host memory (page-locked, shared) does not grow with the clip."""
+                while opened[0] <= min(upto, len(units) - 1):
+                    ui = opened[0]
+                    gi, members, c0, c1 = units[ui]
+                    if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
+                        stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
+                        stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
+                    else:
+                        stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
+                    for b, si in enumerate(members):
+                        for t in range(c0, c1):
+                            slot[segs[si][1][t]] = (ui, t - c0, b)
+                    # decode in the order the launch thread will ask for the frames: the unit's key frames first
+                    for i in ([segs[si][0] for si in members] if c0 == 0 else []) + [segs[si][1][t] for t in range(c0, c1) for si in members]:
+                        submit_load(i)
+                    opened[0] += 1
+
+            if not native:
+                for i in sorted(set(my_keys) | {i for _, frames in segs for i in frames}):
+                    submit_load(i)
             ngroups = len({u[0] for u in units})
             lanes = self._lanes(model, ngroups) if native else None
-            futs = {}
-            for k in keys:                                                         # key frames pass through (evaluator.py:240-244)
-                futs[k] = finishers.submit(lambda k=k, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
+            unit_futs = []
             prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
             for ui, (gi, members, c0, c1) in enumerate(units):
+                open_units(ui + DECODE_AHEAD)
+                if ui >= MAX_UNITS_IN_FLIGHT:          # back-pressure: the GPU renders faster than PNGs are written; a unit holds its label maps,
+                    unit_futs[ui - MAX_UNITS_IN_FLIGHT].result(timeout=IO_TIMEOUT_S)      # frames and a shared output block until its files exist
                 t0 = time.perf_counter()
                 Tc, Bc = c1 - c0, len(members)
                 got = [loads[segs[si][1][t]].result(timeout=IO_TIMEOUT_S) for t in range(c0, c1) for si in members]      # (t, b) order
@@ -558,8 +590,11 @@ class Evaluator:
                     mark.append(round(time.perf_counter() - t_wall, 4))
                     return res
                 seg_fut = finishers.submit(finish)
+                unit_futs.append(seg_fut)
                 for j, i in enumerate(out_frames):
                     futs[i] = (seg_fut, j)
+            for k in keys:
+                submit_load(k)
             tm["units"] = tm.get("units", 0) + len(units)
             for si, (k, frames) in enumerate([] if native else segs):             # any reference-protocol callable
                 t0 = time.perf_counter()
