@@ -285,3 +285,16 @@ def test_every_tuned_choice_names_an_existing_kernel_variant(lib):
         stale = [(shape, op) for shape, entry in table.items() for op, ch in entry.items()
                  if tuple(ch[:10]) + (int(ch[11]), int(ch[12])) not in geoms]
         assert not stale, (dtype, stale[:5])
+
+
+def test_every_kernel_variant_of_the_library_is_used_by_some_plan(lib):
+    """Round 4 pruned csrc/variants.def to the entries some launch plan uses (tools/prune_variants.py): an entry that no plan of
+    the sweep - both test configurations, the three precision modes, every tabled shape and 50 others, with and without the
+    tables - ever launches is dead weight in a 14 MB library and 2+ minutes of build (k_gemm_dma's tiles, FRW = 0, are chosen
+    per GEMM at plan time and do not show up in the launch strings this check reads)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools.variant_usage import usage
+    info, used = usage()
+    unused = [i for i, (prec, g) in enumerate(info) if i not in used and g[0] != 0]
+    assert len(unused) <= 4, [info[i] for i in unused]      # (a handful may fall out of use when a table is re-measured)
