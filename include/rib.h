@@ -234,10 +234,10 @@ int rib_set_graph_replay(rib_handle* h, int enable);
 int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays);
 
 /* ---- build identity (no reference counterpart: the reference is interpreted Python).  A static string
- *   "librib stamp=<lib> shards=<s0>,...,<s7> consistent=<0|1> variants=<n> compiler=<...>"
- * where <lib> is the content hash (csrc/build.py: sha256 over rib.hip, kernels.hip.h, raster.hip.h, variants.def,
- * variants.hip.h, igemm_shard.hip, include/rib.h + flags + compiler version) rib.o was compiled with and <si> the hash
- * shard object i carries; consistent=1 when all eight shard objects carry the hash rib.o expected of them.  bench.py
+ *   "librib stamp=<lib> shards=<s0>,...,<s23> consistent=<0|1> variants=<n> compiler=<...>"
+ * where <lib> is the content hash (csrc/build.py: sha256 over rib.hip, kernels.hip.h, igemm.hip.h, raster.hip.h,
+ * variants.def, variants.hip.h, igemm_shard.hip, include/rib.h + flags + compiler version) rib.o was compiled with and <si> the hash
+ * shard object i carries (24 of them, csrc/variants.hip.h); consistent=1 when all carry the hash rib.o expected of them.  bench.py
  * prints it in its JSON line; tests/test_native_host.py compares it with the hashes of the tracked tree. ---- */
 const char* rib_build_info(void);
 

@@ -25,10 +25,6 @@
 #include <stdint.h>
 #include <type_traits>
 
-#ifndef RIB_UPS_ROLL
-#define RIB_UPS_ROLL 0   // phase-decomposed upsample conv: 0 = 16 steps fully unrolled, 1 = taps of a phase rolled
-#endif
-
 namespace rib {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -676,25 +672,6 @@ __global__ __launch_bounds__(256 * KW, ((PREC == 0 || SPADE) && NF == 2 && MF ==
     for (int kc = kc_begin; kc < kc_end; kc += BK) {
       __syncthreads();
       writeA(false);
-#if RIB_UPS_ROLL
-      // phases unrolled (the accumulator set must be a compile-time choice), the four taps of a phase rolled
-#pragma unroll
-      for (int ph = 0; ph < 4; ++ph) {
-#pragma unroll 1
-        for (int tt = 0; tt < 4; ++tt) {
-          const int buf = tt & 1;
-          storeB(buf);
-          {
-            int nt = ph * 4 + tt + 1, nkc = kc;
-            if (nt == 16) { nt = 0; nkc = kc + BK; }
-            if (nkc < kc_end) loadB(nkc, nt);
-          }
-          if (ph == 0 && tt == 0 && kc + BK < kc_end) prefetchA(kc + BK);
-          __syncthreads();
-          compute_tap((ph >> 1) + (tt >> 1), (ph & 1) + (tt & 1), buf, ph);
-        }
-      }
-#else
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int buf = t & 1;
@@ -706,7 +683,6 @@ __global__ __launch_bounds__(256 * KW, ((PREC == 0 || SPADE) && NF == 2 && MF ==
         const int ph = t >> 2;
         compute_tap((ph >> 1) + ((t >> 1) & 1), (ph & 1) + (t & 1), buf, ph);
       }
-#endif
     }
   } else if constexpr (KS == 1 && TB == 2) {
     // 1x1 with input tile AND filter slice double-buffered: ONE barrier per channel chunk instead of two (a 1x1 chunk is

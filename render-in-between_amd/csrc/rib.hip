@@ -78,7 +78,7 @@ namespace { struct ProfPair { hipEvent_t start = nullptr, stop = nullptr; }; thr
 #if !defined(RIB_BUILD_STAMP) || !defined(RIB_SHARD_STAMP)
 #error "compile through csrc/build.py (-DRIB_BUILD_STAMP / -DRIB_SHARD_STAMP: content hashes of the sources, see build.py)"
 #endif
-// the stamp strings of the eight k_igemm shard objects (igemm_shard.hip) and this object's own
+// the stamp strings of the RIB_NSECTIONS k_igemm shard objects (igemm_shard.hip) and this object's own
 extern "C" {
 #define RIB_X(s) extern const char rib_stamp_section_##s[];
 RIB_FOR_SECTIONS(RIB_X)

@@ -64,7 +64,7 @@ def _build_module():
 def test_library_is_what_the_tracked_sources_build(lib):
     """the measured binary must be the one the tree compiles to.  Every object of librib.so carries
     the content hash of the sources it was compiled from (csrc/build.py); the hashes of the tree as it is now, the hashes
-    found in the .so file and the ones rib_build_info() reports at run time must all agree, for all nine objects."""
+    found in the .so file and the ones rib_build_info() reports at run time must all agree, for every object (rib.o and the shard objects)."""
     b = _build_module()
     want = b.tree_stamps()
     assert b.check() == [], "librib.so / libribmotion.so were not built from this tree: run csrc/build.py"
