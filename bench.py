@@ -249,7 +249,7 @@ def main():
     # ADVICE r03.)  The classes therefore do NOT add up to the timed step: the difference is the dependent-launch gaps.
     flops = G.forward_flops(B, H, W)
     G.profile_begin(kernels=True)
-    nprof = 5 if args.mode == "frame" else 1
+    nprof = 20 if args.mode == "frame" else 1      # (5 steps gave the class time a run-to-run spread of +-3 %)
     for _ in range(nprof):
         step()
     prof = G.profile_collect()
