@@ -4,6 +4,7 @@ import csv, glob, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.prof_ops import plan_names
 d = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # batch of the traced run (tools/prof_ops.py --run --batch B)
 f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 disp = {}
 for r in csv.DictReader(open(f)):
@@ -13,7 +14,7 @@ for r in csv.DictReader(open(f)):
                             "vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "lds": r["LDS_Block_Size"]})
     e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(disp)
-ops = plan_names(1, 512, 512)
+ops = plan_names(B, 512, 512)
 n = len(ops)
 ids = ids[-n:]
 ctrs = [c for c in disp[ids[0]] if c not in ("name", "t0", "t1", "vgpr", "agpr", "lds")]
