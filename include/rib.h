@@ -233,6 +233,19 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
 int rib_set_graph_replay(rib_handle* h, int enable);
 int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays);
 
+/* ---- batch-invariant launch plans (no reference counterpart: the reference renders one frame per call,
+ * PGNR/models/evaluator.py:238-262, so its frames cannot depend on a grouping).  By default every batch size has its own
+ * kernel choices (measured table or cost model: tile variant, split-K, Winograd tile, fused / level-wise SPADE), and a
+ * sample rendered in a batch of 4 differs from the same sample rendered alone by ~1e-5 (other summation order).
+ * rib_set_plan_batch(h, n) with n > 0 makes every plan built afterwards, whatever its batch, follow the choices of batch n:
+ * a launch only grows in its per-sample grid dimension, a sample's arithmetic is the same in every grouping, and the
+ * frames of rib_forward / rib_chain at B = 1, 2, 3, ... are bit-identical per sample (GPU test).  The folder driver
+ * sets n to its group size, so that ragged last groups, other world sizes and --batch 1 all write the same bytes.
+ * n = 0 restores the default.  Plans are rebuilt on demand; the required workspace of a shape may change with n
+ * (query rib_workspace_bytes / rib_chain_workspace_bytes again). ---- */
+int rib_set_plan_batch(rib_handle* h, int n);
+int rib_get_plan_batch(const rib_handle* h);
+
 /* ---- build identity (no reference counterpart: the reference is interpreted Python).  A static string
  *   "librib stamp=<lib> shards=<s0>,...,<s23> consistent=<0|1> variants=<n> compiler=<...>"
  * where <lib> is the content hash (csrc/build.py: sha256 over rib.hip, kernels.hip.h, igemm.hip.h, raster.hip.h,

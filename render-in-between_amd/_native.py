@@ -81,6 +81,8 @@ SIGNATURES = {
     "rib_build_info": (C.c_char_p, []),
     "rib_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "rib_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rib_set_plan_batch": (C.c_int, [C.c_void_p, C.c_int]),
+    "rib_get_plan_batch": (C.c_int, [C.c_void_p]),
 }
 
 

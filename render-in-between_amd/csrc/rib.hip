@@ -617,6 +617,10 @@ struct rib_handle {
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
   int esz() const { return mc16() ? 2 : 4; }                       // bytes per stored activation element
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
+  // rib_set_plan_batch: > 0 = every launch plan, whatever its batch, follows the kernel choices (tuned table / cost model, split-K,
+  // Winograd tile, fused or level-wise SPADE) of THIS batch size, so that a sample's arithmetic does not depend on how many other
+  // samples ran beside it (the folder driver: frames independent of segment grouping and of the world size); 0 = each batch its own
+  int plan_batch = 0;
   std::map<std::array<int, 5>, std::unique_ptr<Plan>> plans;      // key {flags, tuneB, B, H, W}: see get_plan
   // tuned (variant, split-K) per "B,H,W|op name"; consulted before the analytic cost model
   std::map<std::string, std::pair<int, int>> choices;
@@ -1276,7 +1280,7 @@ struct Builder {
     // 256->256 at 64x64 42.4 -> 37.3 us, 512->256 at 64x64 67.4 -> 56.2; 512->512 at 32x32 38.3 -> 41.0 (kept on F(2x2)).
     // RIB_WINO_M = 2 / 4 forces one of them.
     const int wino_force = getenv("RIB_WINO_M") ? atoi(getenv("RIB_WINO_M")) : 0;
-    const int wm = wino_force == 2 || wino_force == 4 ? wino_force : ((long)B * ((Hout + 3) / 4) * ((Wout + 3) / 4) >= 256 ? 4 : 2);
+    const int wm = wino_force == 2 || wino_force == 4 ? wino_force : ((long)TB_() * ((Hout + 3) / 4) * ((Wout + 3) / 4) >= 256 ? 4 : 2);
     const int NP = (wm + 2) * (wm + 2);      // output tile edge, Winograd positions
     const int tilesY = (Hout + wm - 1) / wm, tilesX = (Wout + wm - 1) / wm, ntiles = tilesY * tilesX;
     const std::string gname = opname + (wm == 2 ? ".wino" : ".wino4");
@@ -1404,7 +1408,7 @@ struct Builder {
   bool cond_level_gemm(int level, const Act& cond) {
     static const long max_px = getenv("RIB_COND_GEMM_MAX_PX") ? atol(getenv("RIB_COND_GEMM_MAX_PX")) : 4096;   // 0: off
     const auto it = h->level_groups.find(level);
-    if (it == h->level_groups.end() || it->second.size() < 2 || (long)B * cond.H * cond.W > max_px) return true;
+    if (it == h->level_groups.end() || it->second.size() < 2 || (long)TB_() * cond.H * cond.W > max_px) return true;
     int N = 0; double fl = 0.0;
     for (int gi : it->second) {
       const SpadeGroup& sg = h->spades[gi];
@@ -1415,10 +1419,10 @@ struct Builder {
     const SpadeGroup& first = h->spades[it->second[0]];
     const std::string name = fmt("cond_%d.gammabeta", level);
     Choice ch;
-    ch.v = pick_gemm_dma(h->prec(), B, cond.H * cond.W, N, cond.Cp);
-    if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, N, B, cond.H, cond.W, cond.Cp, false);
+    ch.v = pick_gemm_dma(h->prec(), TB_(), cond.H * cond.W, N, cond.Cp);
+    if (!ch.v) ch = choose_variant(h->prec(), 1, 1, false, false, N, TB_(), cond.H, cond.W, cond.Cp, false);
     {
-      auto ct = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, name.c_str()));
+      auto ct = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, name.c_str()));
       if (ct != h->choices.end()) {
         const Variant& tv = kVariants[ct->second.first];
         if (tv.BF16 != h->prec() || tv.KS != 1 || tv.STRIDE != 1 || tv.UPS || tv.SPADE || tv.NF == 0 || cond.Cp % tv.BK != 0 || ct->second.second != 1) {
@@ -1475,18 +1479,18 @@ struct Builder {
     // Fused (one kernel: gamma/beta GEMM + modulate epilogue) where the map is large; UNFUSED on the
     // small deep maps, where the fused kernel is one long K chain on a handful of workgroups: the
     // GEMM runs as a split-K 1x1 convolution into partial slabs and k_spade_modulate finishes.
-    const Variant* v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, B, Hout, Wout, cond.Cp, false).v;
+    const Variant* v = choose_variant(h->prec(), 1, 1, false, true, sg.npad, TB_(), Hout, Wout, cond.Cp, false).v;
     if (sg.w1_off)      // 16 modulated channels: the one-fragment layout halves the matrix work (first fitting NF = 1 variant)
       for (int i = 0; i < kNumVariants; ++i) {
         const Variant& t = kVariants[i];
         if (t.SPADE && t.NF == 1 && t.BF16 == h->prec() && t.KW == 1 && t.TB == 1 && cond.Cp % t.BK == 0) { v = &t; break; }
       }
     Choice uf;   // unfused candidate
-    const bool small_map = (long)Hout * Wout * B <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
-    if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, B, Hout, Wout, cond.Cp, true);
+    const bool small_map = (long)Hout * Wout * TB_() <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
+    if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, TB_(), Hout, Wout, cond.Cp, true);
     bool unfused = small_map && uf.v != nullptr;
     {
-      auto it = h->choices.find(fmt("%d,%d,%d|%s", B, P->H, P->W, (key + ".spade").c_str()));
+      auto it = h->choices.find(fmt("%d,%d,%d|%s", TB_(), P->H, P->W, (key + ".spade").c_str()));
       if (it != h->choices.end()) {
         const Variant& tv = kVariants[it->second.first];
         const int ts = it->second.second;
@@ -2028,6 +2032,8 @@ inline bool plan_pairs(int B, int flags) {
 Plan* get_plan(rib_handle* h, int B, int H, int W, int flags = 0, int tuneB = 0) {
   const bool labels_only = (flags & PLAN_LABELS) != 0;
   if (!labels_only && !plan_pairs(B, 0)) flags &= ~PLAN_UNPAIRED;      // one frame plan where nothing is paired anyway
+  if (h->plan_batch > 0) tuneB = h->plan_batch;                       // batch-invariant policy (rib_set_plan_batch)
+  if (tuneB == B) tuneB = 0;
   const std::array<int, 5> key = {flags & 3, tuneB, B, H, W};
   auto it = h->plans.find(key);
   if (it != h->plans.end()) return it->second.get();
@@ -2727,6 +2733,15 @@ int rib_set_graph_replay(rib_handle* h, int enable) {
   return RIB_OK;
 }
 
+int rib_set_plan_batch(rib_handle* h, int n) {
+  if (!h || n < 0) return RIB_ERR_INVALID;
+  if (h->plan_batch != n) drop_chain_graphs(h);     // (plans are keyed by the batch they follow: nothing else to drop)
+  h->plan_batch = n;
+  return RIB_OK;
+}
+
+int rib_get_plan_batch(const rib_handle* h) { return h ? h->plan_batch : RIB_ERR_INVALID; }
+
 int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays) {
   if (!h) return RIB_ERR_INVALID;
   if (captures) *captures = (int64_t)h->graph_captures;
@@ -3002,9 +3017,8 @@ int rib_set_choice(rib_handle* h, int B, int H, int W, const char* op_name, int 
   // chains that follow this shape's choices (key {flags, tuneB, batch, H, W})
   for (auto it = h->plans.begin(); it != h->plans.end();) {
     const std::array<int, 5>& k = it->first;
-    const bool labels = (k[0] & PLAN_LABELS) != 0;
     const bool same_hw = k[3] == H && k[4] == W;
-    const bool follows = same_hw && (labels ? k[1] == B : k[2] == B);
+    const bool follows = same_hw && (k[1] > 0 ? k[1] : k[2]) == B;      // the batch whose choices the plan follows
     if (follows) it = h->plans.erase(it); else ++it;
   }
   return RIB_OK;

@@ -29,6 +29,8 @@ Differences from the reference, none of which change a pixel:
 """
 from __future__ import annotations
 
+import collections
+import contextlib
 import os
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -220,11 +222,15 @@ def _list(d, exts):
 
 class Evaluator:
     def __init__(self, cfg, lanes=2, label_fn=None, png_compress_level=None, resize="cv2", batch=None, chunk=4, io_threads=None,
-                 io_mode="process"):
+                 io_mode="process", reproducible=True):
         """batch: independent segments of equal length rendered as ONE chain of that batch size (None: by frame size,
-        `default_batch`; 1: every segment on its own, the round-1..3 behaviour).  Per-sample arithmetic does not depend
-        on the other samples of a batch, but a batch-B plan may pick other tile variants / split-K factors than the
-        batch-1 plan: frames agree with batch 1 to ~1e-5, not bit for bit.
+        `default_batch`; 1: every segment on its own, the round-1..3 behaviour).
+        reproducible (default True): every chain of the call - full groups, the ragged last group of a clip, a rank's
+        smaller share in a multi-GPU run - follows the kernel choices of ONE batch size, the group size
+        (Generator.set_plan_batch / rib_set_plan_batch): a frame's bytes do not depend on which segments were rendered
+        beside it, so N ranks write what one rank writes ("rank r's frames == single-GPU frames bit-for-bit").
+        False: every group size runs its own measured table (a ragged group of 1-3 segments is then a little faster and its
+        frames differ from the batched ones by ~1e-5, i.e. at most one uint8 step on ~2e-3 of the pixels).
         chunk: time steps per rib_chain call (the pipeline's unit is chunk x B frames); 0 = whole segments.
         lanes: independent chains kept in flight on one GPU, each on its own HIP stream with
         its own generator handle (the frames inside a segment stay strictly sequential).
@@ -243,6 +249,7 @@ class Evaluator:
         if io_mode not in ("process", "thread"):
             raise ValueError("io_mode must be 'process' or 'thread'")
         self.io_mode = io_mode
+        self.reproducible = bool(reproducible)
         self.resize = resize
         self.cfg = cfg
         self.lanes = max(1, int(lanes))
@@ -276,6 +283,7 @@ class Evaluator:
             free = st.f_bavail * st.f_frsize
         except OSError:
             free = 0
+        free += sum(b.nbytes for b in _SHM_ALL)             # blocks this process already holds are reused, not allocated again
         if free < need:
             import warnings
             warnings.warn("Evaluator: /dev/shm has %.0f MB free, the shared staging blocks of the worker processes need %.0f MB: "
@@ -322,6 +330,9 @@ class Evaluator:
                 g.import_weights(blob)
             torch.cuda.current_stream(model.device).synchronize()
             self._lane_cache = cache = (model, cache[1], ver)
+        for g, _ in cache[1][1:]:
+            if hasattr(g, "set_plan_batch"):
+                g.set_plan_batch(model.plan_batch)              # clones made by an earlier call may follow another policy
         return cache[1][:max(1, min(self.lanes, nsegs))]
 
     # ---- per-frame host pre-processing (evaluator.py:205-235) --------------------------------
@@ -358,6 +369,20 @@ class Evaluator:
             raise RuntimeError("this model has no GPU rasteriser (rib_rasterise); pass Evaluator(label_fn=...)")
         return rasterise.rasterise_labels(model, frames, self.height, self.width, self.gauss_sigma,
                                           self.skeleton_thres, self.foot_thres)
+
+    @contextlib.contextmanager
+    def _plan_policy(self, model, native):
+        """reproducible: for the length of a call the generator (and, through Generator.clone, its lane clones) follows the
+        kernel choices of the group size at every batch; the handle gets its own setting back afterwards."""
+        if not (native and hasattr(model, "set_plan_batch")):
+            yield
+            return
+        before = model.plan_batch
+        model.set_plan_batch((self.batch or self.default_batch()) if self.reproducible else 0)
+        try:
+            yield
+        finally:
+            model.set_plan_batch(before)
 
     # ---- the driver ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -411,221 +436,227 @@ class Evaluator:
         t_wall = time.perf_counter()
         up = None
         clip_outputs = []                                     # per clip: (names, {frame index: future})
-        for sub in [f for f in sorted(os.listdir(pose_dir)) if os.path.isdir(os.path.join(pose_dir, f))]:
-            print("Evaluating {} .....".format(sub))
-            frames_dir = os.path.join(save_dir, sub)
-            os.makedirs(frames_dir, exist_ok=True)
-            image_list = _list(os.path.join(train_dir, sub), ("jpg", "png"))
-            dain_list = _list(os.path.join(dain_dir, sub), ("jpg", "png"))
-            pose_list = _list(os.path.join(pose_dir, sub), ("json",))
-            sample_rate = sample_rate_of(len(pose_list), len(image_list))
-            seq_len = (len(image_list) - 1) * sample_rate + 1
-            names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
+        # back-pressure is call-wide: at most MAX_UNITS_IN_FLIGHT units (of any clip) are enqueued but not yet written - a unit
+        # holds its label maps and frames on the device and a shared output block on the host until its files exist, and the
+        # GPU renders faster than PNGs get written, so without the window those would pile up over a many-clip folder
+        inflight = collections.deque()
+        tm["peak_units_in_flight"] = 0
+        with self._plan_policy(model, native):
+            for sub in [f for f in sorted(os.listdir(pose_dir)) if os.path.isdir(os.path.join(pose_dir, f))]:
+                print("Evaluating {} .....".format(sub))
+                frames_dir = os.path.join(save_dir, sub)
+                os.makedirs(frames_dir, exist_ok=True)
+                image_list = _list(os.path.join(train_dir, sub), ("jpg", "png"))
+                dain_list = _list(os.path.join(dain_dir, sub), ("jpg", "png"))
+                pose_list = _list(os.path.join(pose_dir, sub), ("json",))
+                sample_rate = sample_rate_of(len(pose_list), len(image_list))
+                seq_len = (len(image_list) - 1) * sample_rate + 1
+                names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
 
-            gtlist = _list(os.path.join(gt_dir, sub), ("jpg", "png")) if gt_dir is not None else None
-            keys, segs = split_segments(seq_len, sample_rate)
-            # this rank's share: a segment is one unit and brings the key frame it starts from along (that frame is
-            # decoded for the chain anyway); a key frame without a segment (the last one) is a unit of its own
-            first_of = {k: si for si, (k, _) in enumerate(segs)}
-            my_segs, my_keys = [], []
-            for k in keys:
-                if unit % world == rank:
-                    my_keys.append(k)
-                    if k in first_of:
-                        my_segs.append(first_of[k])
-                unit += 1
-            segs = [segs[si] for si in my_segs]
-            # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of
-            # the pipeline with one pinned staging buffer that the decode workers fill in place (no stack on the launch
-            # thread, and the upload from pinned memory is asynchronous)
-            units, stage, slot, stage_blk = [], {}, {}, {}
-            if native:
-                B_ = self.batch or self.default_batch()
-                for gi, members in enumerate(self.group_segments(segs, B_)):
-                    T = len(segs[members[0]][1])
-                    step = self.chunk if self.chunk > 0 else T
-                    for c0 in range(0, T, step):
-                        units.append((gi, members, c0, min(T, c0 + step)))
+                gtlist = _list(os.path.join(gt_dir, sub), ("jpg", "png")) if gt_dir is not None else None
+                keys, segs = split_segments(seq_len, sample_rate)
+                # this rank's share: a segment is one unit and brings the key frame it starts from along (that frame is
+                # decoded for the chain anyway); a key frame without a segment (the last one) is a unit of its own
+                first_of = {k: si for si, (k, _) in enumerate(segs)}
+                my_segs, my_keys = [], []
+                for k in keys:
+                    if unit % world == rank:
+                        my_keys.append(k)
+                        if k in first_of:
+                            my_segs.append(first_of[k])
+                    unit += 1
+                segs = [segs[si] for si in my_segs]
+                # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of
+                # the pipeline with one pinned staging buffer that the decode workers fill in place (no stack on the launch
+                # thread, and the upload from pinned memory is asynchronous)
+                units, stage, slot, stage_blk = [], {}, {}, {}
+                if native:
+                    B_ = self.batch or self.default_batch()
+                    for gi, members in enumerate(self.group_segments(segs, B_)):
+                        T = len(segs[members[0]][1])
+                        step = self.chunk if self.chunk > 0 else T
+                        for c0 in range(0, T, step):
+                            units.append((gi, members, c0, min(T, c0 + step)))
 
-            def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
-                dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
-                if i in slot:
-                    ui, t, b = slot[i]
-                    stage[ui][t, b].copy_(dain)
-                    dain = None
-                # evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame
-                # of its segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale
-                # by its size, not by the DAIN frame's
-                ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
-                gt = self.load_image(ref_img)[0] if i % sample_rate == 0 else None
-                pose = self.load_pose(pose_list[i], image_size(ref_img))
-                if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
-                    pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
-                return dain, gt, pose
+                def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
+                    dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
+                    if i in slot:
+                        ui, t, b = slot[i]
+                        stage[ui][t, b].copy_(dain)
+                        dain = None
+                    # evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame
+                    # of its segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale
+                    # by its size, not by the DAIN frame's
+                    ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
+                    gt = self.load_image(ref_img)[0] if i % sample_rate == 0 else None
+                    pose = self.load_pose(pose_list[i], image_size(ref_img))
+                    if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
+                        pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
+                    return dain, gt, pose
 
-            def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot, stage_blk=stage_blk):
-                """The same pre-load in a worker process; its result is unpacked (the DAIN frame copied into its pinned staging
-                slot, arrays wrapped as tensors) by the pool's result thread as soon as it arrives."""
-                from concurrent.futures import Future
-                ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
-                name, off = "", -1
-                if i in slot:                               # the worker decodes straight into the unit's shared staging block
-                    ui, t, b = slot[i]
-                    name, off = stage_blk[ui].name, (t * stage[ui].shape[1] + b) * self.height * self.width * 3
-                src = procs.submit(io_worker.load_frame_shm, name, off, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0,
-                                   gpu_labels, self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
-                out = Future()
+                def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot, stage_blk=stage_blk):
+                    """The same pre-load in a worker process; its result is unpacked (the DAIN frame copied into its pinned staging
+                    slot, arrays wrapped as tensors) by the pool's result thread as soon as it arrives."""
+                    from concurrent.futures import Future
+                    ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
+                    name, off = "", -1
+                    if i in slot:                               # the worker decodes straight into the unit's shared staging block
+                        ui, t, b = slot[i]
+                        name, off = stage_blk[ui].name, (t * stage[ui].shape[1] + b) * self.height * self.width * 3
+                    src = procs.submit(io_worker.load_frame_shm, name, off, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0,
+                                       gpu_labels, self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
+                    out = Future()
 
-                def unpack(f):
-                    try:
-                        _, gt, pose = f.result()
-                        out.set_result((None, torch.from_numpy(io_worker.normalised_chw(gt)) if gt is not None else None, pose))
-                    except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
-                        out.set_exception(e)
-                src.add_done_callback(unpack)
-                return out
-            keys = my_keys
-            loads, futs, opened = {}, {}, [0]
+                    def unpack(f):
+                        try:
+                            _, gt, pose = f.result()
+                            out.set_result((None, torch.from_numpy(io_worker.normalised_chw(gt)) if gt is not None else None, pose))
+                        except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
+                            out.set_exception(e)
+                    src.add_done_callback(unpack)
+                    return out
+                keys = my_keys
+                loads, futs, opened = {}, {}, [0]
 
-            def submit_load(i):
-                if i not in loads:
-                    loads[i] = load_in_worker(i) if procs is not None else pool.submit(load, i)
-                    if i in keys and i not in futs:                                # key frames pass through (evaluator.py:240-244)
-                        futs[i] = finishers.submit(lambda k=i, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
+                def submit_load(i):
+                    if i not in loads:
+                        loads[i] = load_in_worker(i) if procs is not None else pool.submit(load, i)
+                        if i in keys and i not in futs:                                # key frames pass through (evaluator.py:240-244)
+                            futs[i] = finishers.submit(lambda k=i, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
 
-            def open_units(upto):
-                """Staging block, slots and decode tasks of the units up to index `upto`: the launch thread keeps DECODE_AHEAD units
-                open beyond the one it is enqueueing, so that host memory (page-locked, shared) does not grow with the clip."""
-                while opened[0] <= min(upto, len(units) - 1):
-                    ui = opened[0]
-                    gi, members, c0, c1 = units[ui]
-                    if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
-                        stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
-                        stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
-                    else:
-                        stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
-                    for b, si in enumerate(members):
-                        for t in range(c0, c1):
-                            slot[segs[si][1][t]] = (ui, t - c0, b)
-                    # decode in the order the launch thread will ask for the frames: the unit's key frames first
-                    for i in ([segs[si][0] for si in members] if c0 == 0 else []) + [segs[si][1][t] for t in range(c0, c1) for si in members]:
+                def open_units(upto):
+                    """Staging block, slots and decode tasks of the units up to index `upto`: the launch thread keeps DECODE_AHEAD units
+                    open beyond the one it is enqueueing, so that host memory (page-locked, shared) does not grow with the clip."""
+                    while opened[0] <= min(upto, len(units) - 1):
+                        ui = opened[0]
+                        gi, members, c0, c1 = units[ui]
+                        if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
+                            stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
+                            stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
+                        else:
+                            stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
+                        for b, si in enumerate(members):
+                            for t in range(c0, c1):
+                                slot[segs[si][1][t]] = (ui, t - c0, b)
+                        # decode in the order the launch thread will ask for the frames: the unit's key frames first
+                        for i in ([segs[si][0] for si in members] if c0 == 0 else []) + [segs[si][1][t] for t in range(c0, c1) for si in members]:
+                            submit_load(i)
+                        opened[0] += 1
+
+                if not native:
+                    for i in sorted(set(my_keys) | {i for _, frames in segs for i in frames}):
                         submit_load(i)
-                    opened[0] += 1
+                ngroups = len({u[0] for u in units})
+                lanes = self._lanes(model, ngroups) if native else None
+                prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
+                for ui, (gi, members, c0, c1) in enumerate(units):
+                    open_units(ui + DECODE_AHEAD)
+                    while len(inflight) >= MAX_UNITS_IN_FLIGHT:      # back-pressure (call-wide window, above): wait for the oldest unit's files
+                        inflight.popleft().result(timeout=IO_TIMEOUT_S)
+                    t0 = time.perf_counter()
+                    Tc, Bc = c1 - c0, len(members)
+                    got = [loads[segs[si][1][t]].result(timeout=IO_TIMEOUT_S) for t in range(c0, c1) for si in members]      # (t, b) order
+                    gt = torch.stack([loads[segs[si][0]].result(timeout=IO_TIMEOUT_S)[1] for si in members]) if c0 == 0 else None
+                    t1 = time.perf_counter()
+                    tm["load"] += t1 - t0
+                    poses = [g_[2] for g_ in got]
+                    g, st = lanes[gi % len(lanes)] if lanes else (model, torch.cuda.current_stream(model.device))
+                    # uploads (pageable host memory: synchronous with respect to their stream) and the label
+                    # rasterisation go to a stream of their own, which is idle, so that they do not wait behind
+                    # the previous unit of this lane; the lane joins through an event
+                    if up is None:
+                        up = torch.cuda.Stream(device=model.device)
+                    with torch.cuda.stream(up):
+                        if gpu_labels:
+                            lab = rasterise.rasterise_tables(g, poses, self.height, self.width, self.gauss_sigma)
+                        else:
+                            lab = self.make_labels(g if hasattr(g, "rasterise") else model, poses)
+                        lab = lab.to(g.device).reshape(Tc, Bc, *lab.shape[1:])            # [Tc,B,22,H,W]
+                        # ToTensor + Normalize(0.5, 0.5) of the uint8 frames on the GPU (HSM_auto_dataset.py:73-75)
+                        dn = stage[ui].to(g.device, non_blocking=True).permute(0, 1, 4, 2, 3).to(torch.float32)
+                        dn = ((dn / 255.0 - 0.5) / 0.5).contiguous()                      # [Tc,B,3,H,W]
+                        gtd = gt.to(g.device) if gt is not None else None
+                        ready = torch.cuda.Event()
+                        ready.record(up)
+                    for t_ in (lab, dn, gtd):
+                        if t_ is not None:
+                            t_.record_stream(st)
+                    with torch.cuda.stream(st):
+                        st.wait_event(ready)
+                        t2 = time.perf_counter()
+                        # evaluator.py:240-244,252: a segment starts from its key frame; inside it prev <- fused frame
+                        fz = g.chain(gtd if c0 == 0 else prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
+                        prev_of[gi] = fz[-1]
+                        q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
+                        out_blk = _shm_get(q.numel()) if procs is not None else None       # shared with the encode workers, page-locked
+                        pinned = out_blk.t.view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                        pinned.copy_(q, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(st)
+                    tm["rasterise"] += t2 - t1
+                    tm["generate"] += time.perf_counter() - t2
+                    out_frames = [segs[si][1][t] for t in range(c0, c1) for si in members]
 
-            if not native:
-                for i in sorted(set(my_keys) | {i for _, frames in segs for i in frames}):
-                    submit_load(i)
-            ngroups = len({u[0] for u in units})
-            lanes = self._lanes(model, ngroups) if native else None
-            unit_futs = []
-            prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
-            for ui, (gi, members, c0, c1) in enumerate(units):
-                open_units(ui + DECODE_AHEAD)
-                if ui >= MAX_UNITS_IN_FLIGHT:          # back-pressure: the GPU renders faster than PNGs are written; a unit holds its label maps,
-                    unit_futs[ui - MAX_UNITS_IN_FLIGHT].result(timeout=IO_TIMEOUT_S)      # frames and a shared output block until its files exist
-                t0 = time.perf_counter()
-                Tc, Bc = c1 - c0, len(members)
-                got = [loads[segs[si][1][t]].result(timeout=IO_TIMEOUT_S) for t in range(c0, c1) for si in members]      # (t, b) order
-                gt = torch.stack([loads[segs[si][0]].result(timeout=IO_TIMEOUT_S)[1] for si in members]) if c0 == 0 else None
-                t1 = time.perf_counter()
-                tm["load"] += t1 - t0
-                poses = [g_[2] for g_ in got]
-                g, st = lanes[gi % len(lanes)] if lanes else (model, torch.cuda.current_stream(model.device))
-                # uploads (pageable host memory: synchronous with respect to their stream) and the label
-                # rasterisation go to a stream of their own, which is idle, so that they do not wait behind
-                # the previous unit of this lane; the lane joins through an event
-                if up is None:
-                    up = torch.cuda.Stream(device=model.device)
-                with torch.cuda.stream(up):
-                    if gpu_labels:
-                        lab = rasterise.rasterise_tables(g, poses, self.height, self.width, self.gauss_sigma)
-                    else:
-                        lab = self.make_labels(g if hasattr(g, "rasterise") else model, poses)
-                    lab = lab.to(g.device).reshape(Tc, Bc, *lab.shape[1:])            # [Tc,B,22,H,W]
-                    # ToTensor + Normalize(0.5, 0.5) of the uint8 frames on the GPU (HSM_auto_dataset.py:73-75)
-                    dn = stage[ui].to(g.device, non_blocking=True).permute(0, 1, 4, 2, 3).to(torch.float32)
-                    dn = ((dn / 255.0 - 0.5) / 0.5).contiguous()                      # [Tc,B,3,H,W]
-                    gtd = gt.to(g.device) if gt is not None else None
-                    ready = torch.cuda.Event()
-                    ready.record(up)
-                for t_ in (lab, dn, gtd):
-                    if t_ is not None:
-                        t_.record_stream(st)
-                with torch.cuda.stream(st):
-                    st.wait_event(ready)
-                    t2 = time.perf_counter()
-                    # evaluator.py:240-244,252: a segment starts from its key frame; inside it prev <- fused frame
-                    fz = g.chain(gtd if c0 == 0 else prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
-                    prev_of[gi] = fz[-1]
-                    q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
-                    out_blk = _shm_get(q.numel()) if procs is not None else None       # shared with the encode workers, page-locked
-                    pinned = out_blk.t.view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
-                    pinned.copy_(q, non_blocking=True)
-                    done = torch.cuda.Event()
-                    done.record(st)
-                tm["rasterise"] += t2 - t1
-                tm["generate"] += time.perf_counter() - t2
-                out_frames = [segs[si][1][t] for t in range(c0, c1) for si in members]
+                    t_enq = time.perf_counter() - t_wall
 
-                t_enq = time.perf_counter() - t_wall
-
-                def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd), in_blk=stage_blk.get(ui),
-                           out_blk=out_blk, t_enq=t_enq, t_loaded=t1 - t_wall):
-                    done.synchronize()                      # the chain, the quantiser and the download are done: so is the upload
-                    # per unit: inputs decoded, launches enqueued, results on the host, files written (seconds since the call began)
-                    mark = [round(t_loaded, 4), round(t_enq, 4), round(time.perf_counter() - t_wall, 4)]
-                    tm.setdefault("timeline", []).append(mark)
-                    if in_blk is not None:
-                        _shm_put(in_blk)
-                    if out_blk is not None:
-                        fsz = self.height * self.width * 3
-                        fs = [procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, self.height, self.width, names[out_frames[j]], level)
-                              for j in range(len(out_frames))]
-                        res = [f.result(timeout=IO_TIMEOUT_S) for f in fs]
-                        _shm_put(out_blk)
+                    def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd), in_blk=stage_blk.get(ui),
+                               out_blk=out_blk, t_enq=t_enq, t_loaded=t1 - t_wall):
+                        done.synchronize()                      # the chain, the quantiser and the download are done: so is the upload
+                        # per unit: inputs decoded, launches enqueued, results on the host, files written (seconds since the call began)
+                        mark = [round(t_loaded, 4), round(t_enq, 4), round(time.perf_counter() - t_wall, 4)]
+                        tm.setdefault("timeline", []).append(mark)
+                        if in_blk is not None:
+                            _shm_put(in_blk)
+                        if out_blk is not None:
+                            fsz = self.height * self.width * 3
+                            fs = [procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, self.height, self.width, names[out_frames[j]], level)
+                                  for j in range(len(out_frames))]
+                            res = [f.result(timeout=IO_TIMEOUT_S) for f in fs]
+                            _shm_put(out_blk)
+                            mark.append(round(time.perf_counter() - t_wall, 4))
+                            return res
+                        qn = pinned.numpy()
+                        res = list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
                         mark.append(round(time.perf_counter() - t_wall, 4))
                         return res
-                    qn = pinned.numpy()
-                    res = list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
-                    mark.append(round(time.perf_counter() - t_wall, 4))
-                    return res
-                seg_fut = finishers.submit(finish)
-                unit_futs.append(seg_fut)
-                for j, i in enumerate(out_frames):
-                    futs[i] = (seg_fut, j)
-            for k in keys:
-                submit_load(k)
-            tm["units"] = tm.get("units", 0) + len(units)
-            for si, (k, frames) in enumerate([] if native else segs):             # any reference-protocol callable
-                t0 = time.perf_counter()
-                got = [loads[i].result() for i in frames]
-                gt = loads[k].result()[1].unsqueeze(0)
-                t1 = time.perf_counter()
-                tm["load"] += t1 - t0
-                poses = [g[2] for g in got]
-                dn = torch.stack([g[0] for g in got]).unsqueeze(1)
-                lab = self.make_labels(model, poses).unsqueeze(1)
-                t2 = time.perf_counter()
-                prev, outs = gt, []
-                for t in range(len(frames)):
-                    img, mask = model(lab[t], None, dn[t], prev)
-                    prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
-                    outs.append(prev)
-                tm["rasterise"] += t2 - t1
-                tm["generate"] += time.perf_counter() - t2
-                for t, i in enumerate(frames):
-                    futs[i] = pool.submit(save_host, outs[t], names[i])
-            clip_outputs.append((names, futs))
-            tm["frames"] += len(futs)
-        t5 = time.perf_counter()
-        for names, futs in clip_outputs:                                           # frame order, as the reference writes them
-            for i, name in enumerate(names):
-                if i not in futs:
-                    continue                                                       # another rank's frame
-                f = futs[i]
-                res = f[0].result()[f[1]] if isinstance(f, tuple) else f.result()
-                assert res == name
-                written.append(name)
-        tm["save"] = time.perf_counter() - t5                                      # tail: encodes still running after the last enqueue
-        tm["wall"] = time.perf_counter() - t_wall
+                    seg_fut = finishers.submit(finish)
+                    inflight.append(seg_fut)
+                    tm["peak_units_in_flight"] = max(tm["peak_units_in_flight"], len(inflight))
+                    for j, i in enumerate(out_frames):
+                        futs[i] = (seg_fut, j)
+                for k in keys:
+                    submit_load(k)
+                tm["units"] = tm.get("units", 0) + len(units)
+                for si, (k, frames) in enumerate([] if native else segs):             # any reference-protocol callable
+                    t0 = time.perf_counter()
+                    got = [loads[i].result() for i in frames]
+                    gt = loads[k].result()[1].unsqueeze(0)
+                    t1 = time.perf_counter()
+                    tm["load"] += t1 - t0
+                    poses = [g[2] for g in got]
+                    dn = torch.stack([g[0] for g in got]).unsqueeze(1)
+                    lab = self.make_labels(model, poses).unsqueeze(1)
+                    t2 = time.perf_counter()
+                    prev, outs = gt, []
+                    for t in range(len(frames)):
+                        img, mask = model(lab[t], None, dn[t], prev)
+                        prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
+                        outs.append(prev)
+                    tm["rasterise"] += t2 - t1
+                    tm["generate"] += time.perf_counter() - t2
+                    for t, i in enumerate(frames):
+                        futs[i] = pool.submit(save_host, outs[t], names[i])
+                clip_outputs.append((names, futs))
+                tm["frames"] += len(futs)
+            t5 = time.perf_counter()
+            for names, futs in clip_outputs:                                           # frame order, as the reference writes them
+                for i, name in enumerate(names):
+                    if i not in futs:
+                        continue                                                       # another rank's frame
+                    f = futs[i]
+                    res = f[0].result()[f[1]] if isinstance(f, tuple) else f.result()
+                    assert res == name
+                    written.append(name)
+            tm["save"] = time.perf_counter() - t5                                      # tail: encodes still running after the last enqueue
+            tm["wall"] = time.perf_counter() - t_wall
         return written

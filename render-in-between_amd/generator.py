@@ -67,6 +67,7 @@ class Generator:
         self._h = h
         _native.check(h, self._lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1, "f16": 3}[compute_dtype]))
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._plan_batch = 0
         self._tuned: Dict[tuple, int] = {}      # (B,H,W) -> launches whose variant came from the measured table
         self.training = False
         self._graph_replay = bool(int(__import__("os").environ.get("RIB_GRAPH", "0") or 0))
@@ -146,6 +147,7 @@ class Generator:
         of the blob): used to keep several independent segments in flight on separate HIP streams
         (a handle is single-stream)."""
         g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning, compute_dtype=self.compute_dtype)
+        g.set_plan_batch(self._plan_batch)
         blob = self.export_weights()
         g.import_weights(blob)
         torch.cuda.current_stream(self.device).synchronize()
@@ -164,20 +166,38 @@ class Generator:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_plan_batch(self, n):
+        """Batch-invariant launch plans (rib_set_plan_batch, include/rib.h): with n > 0 every plan, whatever its batch, follows
+        the kernel choices of batch n, so a sample's frames are bit-identical in every grouping (B = 1, a ragged group of 3,
+        a full group); 0 = every batch its own choices (the default of a handle; fastest for a single call)."""
+        n = max(0, int(n))
+        if n != self._plan_batch:
+            _native.check(self._h, self._lib.rib_set_plan_batch(self._h, n))
+            self._plan_batch = n
+            self._ws.clear()                     # the workspace a shape needs follows the plans
+            self.__dict__.pop("_chain_ws", None)
+            self.__dict__.pop("_chain_out", None)
+        return self
+
+    @property
+    def plan_batch(self):
+        return self._plan_batch
+
     def _workspace(self, B, H, W):
         key = (B, H, W)
         ws = self._ws.get(key)
         if ws is None:
+            TB = self._plan_batch or B           # the batch whose measured choices this shape's plans follow
             if self._use_tuning:
                 from . import tuning
                 if self._tuning is None:
                     self._tuning = tuning.load(dtype=self.compute_dtype)
-                self._tuned[key] = tuning.apply(self._lib, self._h, self._tuning, B, H, W, dtype=self.compute_dtype)
+                self._tuned[key] = tuning.apply(self._lib, self._h, self._tuning, TB, H, W, dtype=self.compute_dtype)
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
-            if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (B, H, W)):
+            if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (TB, H, W)):
                 # a stale tuning entry must never break the path: drop it and use the cost model
-                for op in self._tuning["%d,%d,%d" % (B, H, W)]:
-                    self._lib.rib_set_choice(self._h, B, H, W, op.encode(), -1, 1)
+                for op in self._tuning["%d,%d,%d" % (TB, H, W)]:
+                    self._lib.rib_set_choice(self._h, TB, H, W, op.encode(), -1, 1)
                 n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0:
                 _native.check(self._h, -1)

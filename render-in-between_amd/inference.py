@@ -59,6 +59,22 @@ def load_generator(config, device=None, rank=0, world=1, dtype="f32"):
     return net_G
 
 
+def summary_line(evaluator, rank=0, world=1):
+    """One line per rank at the end of a run: what was rendered and where the wall time went.  The phases are the launch
+    thread's waits (load: for decoded inputs; rasterise + generate: enqueueing the GPU work; save: the encode tail after the
+    last enqueue); the file-side work itself runs in `workers` processes on `cpu_budget` cores beside them."""
+    from render_in_between_amd.evaluator import cpu_budget
+    tm = evaluator.timings
+    wall = max(tm.get("wall", 0.0), 1e-9)
+    return ("[rank %d/%d] %d frames in %.2f s = %.1f frames/s | load %.2f s, rasterise %.2f s, generate %.2f s, save tail %.2f s | "
+            "%d units, <= %d in flight | %d file workers (%s), CPU budget %d cores | PNG level %s, batch %d, %s plans"
+            % (rank, world, tm.get("frames", 0), wall, tm.get("frames", 0) / wall, tm.get("load", 0.0), tm.get("rasterise", 0.0),
+               tm.get("generate", 0.0), tm.get("save", 0.0), tm.get("units", 0), tm.get("peak_units_in_flight", 0),
+               evaluator.io_threads, evaluator.io_mode, cpu_budget(),
+               "reference (zlib 6)" if evaluator.png_compress_level is None else str(evaluator.png_compress_level),
+               evaluator.batch or evaluator.default_batch(), "batch-invariant" if evaluator.reproducible else "per-batch"))
+
+
 def main(opts):
     from render_in_between_amd import distributed as ribdist
     if opts.gpus > 1 and not ribdist.is_rank_process():
@@ -77,12 +93,14 @@ def main(opts):
         torch.cuda.set_device(device)
         ribdist.init_process_group(os.environ.get("RIB_DIST_BACKEND"), device)
     net_G = load_generator(config, device, rank, world, opts.dtype)
-    evaluator = Evaluator(config, batch=opts.batch or None)
+    evaluator = Evaluator(config, batch=opts.batch or None, reproducible=opts.reproducible,
+                          png_compress_level=None if opts.png_level == "reference" else int(opts.png_level))
     train_dir = os.path.join(opts.input_dir, "inputs")
     dain_dir = os.path.join(opts.input_dir, "DAIN")
     pose_dir = os.path.join(opts.input_dir, "Predict_motion")
     save_dir = os.path.join(opts.save_dir, "Generated_frames")
     written = evaluator.evaluate_from_folder(net_G, train_dir, dain_dir, pose_dir, save_dir, gt_dir=None, gen_vid=False)
+    print(summary_line(evaluator, rank, world))
     if world > 1:
         print("[rank {}/{}] wrote {} frames".format(rank, world, len(written)))
         torch.distributed.barrier()
@@ -101,5 +119,16 @@ if __name__ == "__main__":
     parser.add_argument("--gpus", type=int, default=1, help="ranks to start, one per GPU (not in the reference: it is single-device)")
     parser.add_argument("--batch", type=int, default=0,
                         help="independent segments rendered as one chain of that batch size (0: by frame size - 8 at 320x480, 4 at 512x512; "
-                             "1: one chain per segment, which also makes an N-rank run byte-identical to a 1-rank run)")
-    main(parser.parse_args())
+                             "1: one chain per segment)")
+    parser.add_argument("--png-level", default="reference",
+                        help="'reference' (default): PIL's default deflate level 6, the very bytes PGNR/utils/utils.py:139-142 writes - 54 ms of "
+                             "CPU per 512x512 frame, i.e. the end-to-end rate is bound by the host cores (~200 frames/s on 16); 0-9: that zlib "
+                             "level - same pixels, other file bytes (1: ~2x the end-to-end rate, ~25 %% larger files)")
+    parser.add_argument("--reproducible", action=argparse.BooleanOptionalAction, default=True,
+                        help="(default) every group size follows the kernel choices of the full group, so a frame's bytes do not depend "
+                             "on segment grouping, on --gpus N or on --batch 1 vs N-rank shares; --no-reproducible lets ragged groups "
+                             "run their own measured tables (frames then agree to ~1e-5, at most one uint8 step)")
+    opts = parser.parse_args()
+    if opts.png_level != "reference" and opts.png_level not in [str(i) for i in range(10)]:
+        parser.error("--png-level must be 'reference' or a zlib level 0-9")
+    main(opts)

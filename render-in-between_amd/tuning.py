@@ -43,6 +43,7 @@ def apply(lib, handle, table, B, H, W, dtype="f32"):
         if lib.rib_variant_info(i, g11) == PREC[dtype]:
             geoms[tuple(g11)] = i
     n = 0
+    skipped = []
     for op, choice in entry.items():
         # entry = geometry[10] + [ksplit] (+ [KW, TB]: wave groups per workgroup, filter slices per
         # barrier; 1 when absent)
@@ -50,7 +51,17 @@ def apply(lib, handle, table, B, H, W, dtype="f32"):
         tb = int(choice[12]) if len(choice) > 12 else 1
         idx = geoms.get(tuple(choice[:10]) + (kwg, tb))
         if idx is None:
-            continue                      # variant table changed since tuning: model choice
+            skipped.append(op)            # variant table changed since tuning: model choice
+            continue
         if lib.rib_set_choice(handle, B, H, W, op.encode(), idx, int(choice[10])) == 0:
             n += 1
+    last_skipped[(dtype, B, H, W)] = skipped
+    if skipped:
+        import warnings
+        warnings.warn("tuning table %s: %d of %d entries of shape %d,%d,%d name a kernel geometry this library does not have "
+                      "(%s ...): those launches take the cost model's choice; re-run tools/autotune.py for this build"
+                      % (dtype, len(skipped), len(entry), B, H, W, skipped[0]))
     return n
+
+
+last_skipped = {}           # (dtype, B, H, W) -> op names whose tabled geometry the loaded library lacks (apply())

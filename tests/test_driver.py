@@ -18,21 +18,21 @@ MID_CFG = dict(num_filters=16, max_num_filters=64, mask=dict(num_filters=32, max
                embed=dict(num_filters=32, max_num_filters=64))
 
 
-def _write_example(root, n_key=2, rate=2, H=32, W=48):
+def _write_example(root, n_key=2, rate=2, H=32, W=48, clip="clipA", seed=0):
     from PIL import Image
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     n = (n_key - 1) * rate + 1
     for d in ("inputs", "DAIN", "Predict_motion"):
-        os.makedirs(os.path.join(root, d, "clipA"))
+        os.makedirs(os.path.join(root, d, clip))
     for k in range(n_key):
-        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "inputs", "clipA", "%04d.png" % k))
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "inputs", clip, "%04d.png" % k))
     for i in range(n):
-        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "DAIN", "clipA", "f%03d.png" % i))
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, "DAIN", clip, "f%03d.png" % i))
         body = []
         for j in range(25):
             body += [float(rng.uniform(4, W - 4)), float(rng.uniform(4, H - 4)), 0.9]
         hand = [10.0, 10.0, 0.9] * 21
-        with open(os.path.join(root, "Predict_motion", "clipA", "f%03d_keypoints.json" % i), "w") as f:
+        with open(os.path.join(root, "Predict_motion", clip, "f%03d_keypoints.json" % i), "w") as f:
             json.dump({"people": [{"pose_keypoints_2d": body, "hand_left_keypoints_2d": hand, "hand_right_keypoints_2d": hand}]}, f)
     return n
 
