@@ -1531,58 +1531,122 @@ __global__ __launch_bounds__(256) void k_quantise(const float* img, uint8_t* out
 // Bilinear flow warp == grid_sample(img, base + flow*2/(size-1), bilinear, border, align_corners=True)
 // i.e. sample img at (x + fx, y + fy) in pixel units with border clamping.  Extension op (the north star
 // names it, the reference has no such call), pinned to torch's grid_sample.
-// A workgroup owns a 16 x 16 tile of OUTPUT pixels and stages the (16 + 2R) x (16 + 2R) window of the source around
-// it (R = WARP_R pixels of flow reach, all channels, border-clamped coordinates) in LDS with reads that are coalesced
-// along x within each channel plane (the driver holds frames NCHW, as the reference does: x-contiguous planes; for
-// C = 3 that is the coalesced order - an interleaved NHWC frame would be 12-byte pixels).  A pixel whose four taps
-// fall inside the window reads them from LDS (each source pixel is fetched from HBM once per tile instead of up to
-// four times per channel through the vector cache); a pixel whose flow reaches further than R falls back to global
-// loads, so any flow field is handled.  Same arithmetic on both paths.  grid (tilesX * tilesY, B), block 256.
-enum { WARP_R = 8, WARP_T = 16, WARP_WIN = WARP_T + 2 * WARP_R };
+// Round 5 (the round-4 kernel: 16 x 16 tiles under a 32 x 32 window = 4x the source bytes through the caches, 2.3x the
+// algorithmic HBM traffic, 0.22-0.27 of the HBM roof): a workgroup owns a 64 x 32 tile of OUTPUT pixels and stages the
+// (64 + 2R) x (32 + 2R) window of the source around it (R = WARP_R pixels of flow reach, all channels, border-clamped
+// coordinates: 1.9x the tile instead of 4x) in LDS as 16-byte row segments (the frames are NCHW, x-contiguous planes; rows
+// and the window origin are 16-byte aligned when W % 4 == 0, else element by element); workgroups take tiles in an
+// XCD-aware order (block b -> tile (b % 8) * tiles / 8 + b / 8), so that the halo rows two vertically adjacent tiles share
+// are fetched by ONE L2.  A thread renders two rows of 4 consecutive pixels: the flow is read once per pixel as two
+// float4 (shared by all channels), the result stored as one float4 per channel and row.  A pixel whose four taps fall
+// inside the window reads them from LDS; a pixel whose flow reaches further than R takes global loads, so any flow field is
+// handled; same arithmetic on both paths.  The sampling position follows torch's own fp32 steps - base grid as
+// torch.linspace(-1, 1, size) builds it (start + step i below the middle, end - step (size - 1 - i) above), offset
+// (flow * 2) / (size - 1), un-normalisation ((g + 1) / 2) (size - 1), weights (1 - w) as grid_sample's CPU kernel forms them
+// - so that a 1024-wide frame agrees with grid_sample to ~1e-5 (a base grid computed as 2 x / (W - 1) - 1 is off by an ulp
+// of 1, i.e. 1e-4 pixels at that width).  grid (tilesX * tilesY, B), block 256.
+// Measured (profiles/r05_warp*.json): bit-identical to grid_sample on 512x512 / 1024x1024 frames; HBM-side traffic 1.05-1.09x
+// the algorithmic bytes (round 4: 2.3x); 1024x1024 batch 4: 48 us = 2.8 TB/s = 0.35 of the 8 TB/s roof (0.27).  What is left:
+// ~180 vector instructions per pixel (two IEEE divisions among them, kept for the exact sampling position) keep the vector
+// ALUs busy 40 % of the launch, and a workgroup stages, then computes - a 16-row tile (5 workgroups per CU) is no faster; the
+// next step would be a persistent workgroup that stages tile t + 1 under the arithmetic of tile t.
+enum { WARP_R = 8, WARP_TW = 64, WARP_TH = 32, WARP_WW = WARP_TW + 2 * WARP_R, WARP_WH = WARP_TH + 2 * WARP_R, WARP_PITCH = WARP_WW + 4 };
+
+__device__ __forceinline__ float warp_linspace(int i, int size) {      // torch.linspace(-1, 1, size)[i] in fp32
+  if (size <= 1) return -1.f;
+  const float step = 2.f / (float)(size - 1);
+  return i < size / 2 ? -1.f + step * (float)i : 1.f - step * (float)(size - 1 - i);
+}
 
 __global__ __launch_bounds__(256) void k_warp(const float* img, const float* flow, float* out,
-                                              int C, int H, int W, int tilesX) {
-  extern __shared__ __attribute__((aligned(16))) float s_win[];     // [C][WARP_WIN][WARP_WIN + 1]
-  constexpr int PITCH = WARP_WIN + 1;
+                                              int C, int H, int W, int tilesX, int xcd_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float s_win[];     // [C][WARP_WH][WARP_PITCH]
   const int n = blockIdx.y;
-  const int ty0 = (blockIdx.x / tilesX) * WARP_T, tx0 = (blockIdx.x % tilesX) * WARP_T;
+  const int tile = xcd_chunk > 0 ? (blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3) : blockIdx.x;
+  const int ty0 = (tile / tilesX) * WARP_TH, tx0 = (tile % tilesX) * WARP_TW;
   const int wy0 = ty0 - WARP_R, wx0 = tx0 - WARP_R;
   const int HW = H * W;
   const float* src = img + (size_t)n * C * HW;
-  for (int i = threadIdx.x; i < C * WARP_WIN * WARP_WIN; i += 256) {
-    const int c = i / (WARP_WIN * WARP_WIN), r = i % (WARP_WIN * WARP_WIN);
-    const int wy = r / WARP_WIN, wx = r % WARP_WIN;
-    const int sy = min(max(wy0 + wy, 0), H - 1), sx = min(max(wx0 + wx, 0), W - 1);   // border padding = clamped coordinates
-    s_win[(c * WARP_WIN + wy) * PITCH + wx] = src[(size_t)c * HW + sy * W + sx];
+  const bool vec = (W & 3) == 0;      // rows start 16-byte aligned (hipMalloc'd tensors; wx0 is a multiple of 4)
+  constexpr int SEG = WARP_WW / 4;
+  for (int i = threadIdx.x; i < C * WARP_WH * SEG; i += 256) {
+    const int c = i / (WARP_WH * SEG), r = i - c * (WARP_WH * SEG);
+    const int wy = r / SEG, sg = r - wy * SEG;
+    const int sy = min(max(wy0 + wy, 0), H - 1), xs = wx0 + 4 * sg;   // border padding = clamped coordinates
+    const float* row = src + (size_t)c * HW + (size_t)sy * W;
+    float4 v;
+    if (vec && xs >= 0 && xs + 3 < W) v = *reinterpret_cast<const float4*>(row + xs);
+    else v = make_float4(row[min(max(xs, 0), W - 1)], row[min(max(xs + 1, 0), W - 1)], row[min(max(xs + 2, 0), W - 1)], row[min(max(xs + 3, 0), W - 1)]);
+    *reinterpret_cast<float4*>(s_win + (c * WARP_WH + wy) * WARP_PITCH + 4 * sg) = v;
   }
   __syncthreads();
-  const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
-  if (y >= H || x >= W) return;
-  const int pix = y * W + x;
-  // grid_sample un-normalises in fp32: ((g+1)/2)*(size-1) with g = base + flow*2/(size-1)
-  const float gx = (W > 1 ? (2.f * x / (W - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 0) * HW + pix] * (W > 1 ? 2.f / (W - 1) : 0.f);
-  const float gy = (H > 1 ? (2.f * y / (H - 1) - 1.f) : 0.f) + flow[((size_t)n * 2 + 1) * HW + pix] * (H > 1 ? 2.f / (H - 1) : 0.f);
-  float sx = (gx + 1.f) * 0.5f * (W - 1);
-  float sy = (gy + 1.f) * 0.5f * (H - 1);
-  sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
-  sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
-  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-  const float ax = sx - x0, ay = sy - y0;
-  const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
-  // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
-  const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
-  const bool in_win = lx0 >= 0 && lx1 < WARP_WIN && ly0 >= 0 && ly1 < WARP_WIN;
-  for (int c = 0; c < C; ++c) {
-    float v00, v01, v10, v11;
-    if (in_win) {
-      const float* wsrc = s_win + c * WARP_WIN * PITCH;
-      v00 = wsrc[ly0 * PITCH + lx0]; v01 = wsrc[ly0 * PITCH + lx1]; v10 = wsrc[ly1 * PITCH + lx0]; v11 = wsrc[ly1 * PITCH + lx1];
+  const int x = tx0 + 4 * (threadIdx.x & 15);
+  const float fw = (float)(W - 1), fh = (float)(H - 1);
+#pragma unroll
+  for (int k = 0; k < WARP_TH / 16; ++k) {
+    const int y = ty0 + (threadIdx.x >> 4) + 16 * k;
+    if (y >= H || x >= W) continue;
+    const size_t pix = (size_t)y * W + x;
+    const bool full = vec && x + 3 < W;
+    float fx[4], fy[4];
+    if (full) {
+      const float4 a = *reinterpret_cast<const float4*>(flow + ((size_t)n * 2 + 0) * HW + pix);
+      const float4 b = *reinterpret_cast<const float4*>(flow + ((size_t)n * 2 + 1) * HW + pix);
+      fx[0] = a.x; fx[1] = a.y; fx[2] = a.z; fx[3] = a.w; fy[0] = b.x; fy[1] = b.y; fy[2] = b.z; fy[3] = b.w;
     } else {
-      const float* p = src + (size_t)c * HW;
-      v00 = p[y0 * W + x0]; v01 = p[y0 * W + x1]; v10 = p[y1 * W + x0]; v11 = p[y1 * W + x1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t q = (size_t)y * W + min(x + j, W - 1);
+        fx[j] = flow[((size_t)n * 2 + 0) * HW + q]; fy[j] = flow[((size_t)n * 2 + 1) * HW + q];
+      }
     }
-    out[((size_t)n * C + c) * HW + pix] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    const float by = warp_linspace(y, H);
+    float w00[4], w01[4], w10[4], w11[4];
+    int o00[4], o01[4], o10[4], o11[4];      // tap offsets: into the window (in_win) or into a channel plane
+    bool in_win[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // grid_sample un-normalises in fp32: ((g + 1) / 2) * (size - 1) with g = base + flow * 2 / (size - 1)
+      const float gx = warp_linspace(min(x + j, W - 1), W) + (W > 1 ? (fx[j] * 2.f) / fw : 0.f);
+      const float gy = by + (H > 1 ? (fy[j] * 2.f) / fh : 0.f);
+      float sx = ((gx + 1.f) / 2.f) * fw, sy = ((gy + 1.f) / 2.f) * fh;
+      sx = fminf(fmaxf(sx, 0.f), fw);
+      sy = fminf(fmaxf(sy, 0.f), fh);
+      const float xf = floorf(sx), yf = floorf(sy);
+      const int x0 = (int)xf, y0 = (int)yf;
+      const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+      const float ax = sx - xf, ay = sy - yf, ex = 1.f - ax, ey = 1.f - ay;
+      w00[j] = ex * ey; w01[j] = ax * ey; w10[j] = ex * ay; w11[j] = ax * ay;
+      // window slot of source column / row s: the window holds clamp(w0 + k) at slot k, so an in-image s sits at s - w0
+      const int lx0 = x0 - wx0, lx1 = x1 - wx0, ly0 = y0 - wy0, ly1 = y1 - wy0;
+      in_win[j] = lx0 >= 0 && lx1 < WARP_WW && ly0 >= 0 && ly1 < WARP_WH;
+      if (in_win[j]) { o00[j] = ly0 * WARP_PITCH + lx0; o01[j] = ly0 * WARP_PITCH + lx1; o10[j] = ly1 * WARP_PITCH + lx0; o11[j] = ly1 * WARP_PITCH + lx1; }
+      else { o00[j] = y0 * W + x0; o01[j] = y0 * W + x1; o10[j] = y1 * W + x0; o11[j] = y1 * W + x1; }
+    }
+    // (the two tap sources are kept apart: a pointer selected between LDS and global memory is a generic pointer, and its loads
+    // go down the flat path - 145 vector-memory instructions per wavefront instead of LDS reads, round 5's first version)
+    const bool all_win = in_win[0] && in_win[1] && in_win[2] && in_win[3];
+    for (int c = 0; c < C; ++c) {
+      const float* wsrc = s_win + c * WARP_WH * WARP_PITCH;
+      const float* gsrc = src + (size_t)c * HW;
+      float r[4];
+      if (__all(all_win)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = wsrc[o00[j]] * w00[j] + wsrc[o01[j]] * w01[j] + wsrc[o10[j]] * w10[j] + wsrc[o11[j]] * w11[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (in_win[j]) r[j] = wsrc[o00[j]] * w00[j] + wsrc[o01[j]] * w01[j] + wsrc[o10[j]] * w10[j] + wsrc[o11[j]] * w11[j];
+          else r[j] = gsrc[o00[j]] * w00[j] + gsrc[o01[j]] * w01[j] + gsrc[o10[j]] * w10[j] + gsrc[o11[j]] * w11[j];
+        }
+      }
+      float* dst = out + ((size_t)n * C + c) * HW + pix;
+      if (full) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (x + j < W) dst[j] = r[j];
+      }
+    }
   }
 }
 

@@ -2609,9 +2609,11 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
   if (!h || !img || !flow || !out) return RIB_ERR_INVALID;
   if (h->device >= 0) HIP_TRY(h, hipSetDevice(h->device));
   if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
-  const int tilesX = (W + WARP_T - 1) / WARP_T, tilesY = (H + WARP_T - 1) / WARP_T;
-  const size_t lds = (size_t)C * WARP_WIN * (WARP_WIN + 1) * sizeof(float);
-  RIB_KLAUNCH(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX);
+  const int tilesX = (W + WARP_TW - 1) / WARP_TW, tilesY = (H + WARP_TH - 1) / WARP_TH;
+  const size_t lds = (size_t)C * WARP_WH * WARP_PITCH * sizeof(float);      // 16 KB per channel
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WARP_WH * WARP_PITCH * (int)sizeof(float));
+  if (attr != hipSuccess) return fail(h, RIB_ERR_HIP, fmt("rib_warp: %s", hipGetErrorString(attr)));
+  RIB_KLAUNCH(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX, xcd_chunk_of(tilesX * tilesY));
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;
 }

@@ -206,6 +206,21 @@ def test_warp_extension_matches_grid_sample():
         ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
         out = G.warp(img, flow).cpu()
         assert float((out - ref).abs().max()) <= 5e-5, (B, H, W, amp)
+    # full-size frames (the round-4 kernel was 2.3e-4 off at 1024x1024 - its base grid 2x/(W-1) - 1 differs from
+    # torch.linspace by an ulp of 1, i.e. 1e-4 pixels at that width): white-noise image = the steepest gradients a [-1, 1] frame has,
+    # smooth +-3 px flow (every tap in the staged window), +-40 px flow (every pixel on the global-load path), a width that is
+    # not a multiple of 4 (element-wise staging / stores) and one that does not tile
+    for (B, H, W, amp, seed) in ((2, 1024, 1024, 3.0, 11), (1, 1024, 1024, 40.0, 12), (1, 510, 1022, 6.0, 13), (1, 250, 333, 9.0, 14)):
+        g = torch.Generator().manual_seed(seed)
+        img = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+        low = torch.randn(B, 2, max(1, H // 32), max(1, W // 32), generator=g)
+        flow = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False).clamp(-1, 1) * amp
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+        grid = torch.stack([xs, ys], -1)[None].repeat(B, 1, 1, 1)
+        grid = grid + torch.stack([flow[:, 0] * 2 / (W - 1), flow[:, 1] * 2 / (H - 1)], -1)
+        ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+        out = G.warp(img, flow).cpu()
+        assert float((out - ref).abs().max()) <= 5e-5, (B, H, W, amp)
     # zero flow is the identity (up to the fp32 un-normalisation of the sampling grid)
     assert float((G.warp(img, torch.zeros_like(flow)).cpu() - img).abs().max()) <= 1e-4
     # eight channels (the most rib_warp takes: 34 KB of staged window)
