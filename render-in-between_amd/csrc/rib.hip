@@ -627,7 +627,7 @@ struct rib_handle {
   // profiling
   // rib_chain graph replay (rib_set_graph_replay / RIB_GRAPH=1): instantiated graphs of whole segments, keyed by everything a
   // launch parameter depends on - the shape and every pointer of the call; least recently used first out
-  struct ChainGraph { std::array<uintptr_t, 12> key; hipGraphExec_t exec; uint64_t used; };
+  struct ChainGraph { std::array<uintptr_t, 12> key; hipGraphExec_t exec; uint64_t used; hipStream_t stream; };   // stream: of its last launch
   std::vector<ChainGraph> chain_graphs;
   bool graph_replay = false;
   uint64_t graph_clock = 0, graph_captures = 0, graph_replays = 0;
@@ -657,8 +657,14 @@ namespace {
   } while (0)
 
 // instantiated chain graphs hold the plans' kernel parameters: whatever rebuilds plans or moves the blob drops them
+// an instantiated graph may still be queued or running on the stream of its last launch (the launch only enqueues): that stream
+// is drained before the executable goes away (evictions and plan changes are rare; a replay never comes here)
+void destroy_chain_graph(rib_handle::ChainGraph& g) {
+  if (g.stream) (void)hipStreamSynchronize(g.stream);
+  (void)hipGraphExecDestroy(g.exec);
+}
 void drop_chain_graphs(rib_handle* h) {
-  for (auto& g : h->chain_graphs) (void)hipGraphExecDestroy(g.exec);
+  for (auto& g : h->chain_graphs) destroy_chain_graph(g);
   h->chain_graphs.clear();
 }
 
@@ -2770,7 +2776,7 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
                                          (uintptr_t)workspace_bytes};
   for (auto& g : h->chain_graphs)
     if (g.key == key) {
-      g.used = ++h->graph_clock; ++h->graph_replays;
+      g.used = ++h->graph_clock; ++h->graph_replays; g.stream = st;
       HIP_TRY(h, hipGraphLaunch(g.exec, st));
       return RIB_OK;
     }
@@ -2790,10 +2796,10 @@ int rib_chain(rib_handle* h, int T, int B, int H, int W, const float* key_frame,
   if (h->chain_graphs.size() >= 8) {
     size_t lru = 0;
     for (size_t i = 1; i < h->chain_graphs.size(); ++i) if (h->chain_graphs[i].used < h->chain_graphs[lru].used) lru = i;
-    (void)hipGraphExecDestroy(h->chain_graphs[lru].exec);
+    destroy_chain_graph(h->chain_graphs[lru]);
     h->chain_graphs.erase(h->chain_graphs.begin() + lru);
   }
-  h->chain_graphs.push_back({key, exec, ++h->graph_clock});
+  h->chain_graphs.push_back({key, exec, ++h->graph_clock, st});
   ++h->graph_captures;
   HIP_TRY(h, hipGraphLaunch(exec, st));
   return RIB_OK;

@@ -333,6 +333,8 @@ class Evaluator:
         for g, _ in cache[1][1:]:
             if hasattr(g, "set_plan_batch"):
                 g.set_plan_batch(model.plan_batch)              # clones made by an earlier call may follow another policy
+            if getattr(g, "_graph_replay", False):
+                g.set_graph_replay(False)                       # (_plan_policy: no replay in the folder driver)
         return cache[1][:max(1, min(self.lanes, nsegs))]
 
     # ---- per-frame host pre-processing (evaluator.py:205-235) --------------------------------
@@ -373,16 +375,25 @@ class Evaluator:
     @contextlib.contextmanager
     def _plan_policy(self, model, native):
         """reproducible: for the length of a call the generator (and, through Generator.clone, its lane clones) follows the
-        kernel choices of the group size at every batch; the handle gets its own setting back afterwards."""
+        kernel choices of the group size at every batch; the handle gets its own setting back afterwards.
+        Graph replay (RIB_GRAPH=1 / set_graph_replay) is off for the call: every unit of the pipeline brings fresh label / DAIN
+        tensors, i.e. other pointers, so each chain would capture and instantiate a graph of its own and none would ever
+        replay - the launch-by-launch path is the faster one here; `bench.py --mode clips --graph` is where a
+        segment is replayed."""
         if not (native and hasattr(model, "set_plan_batch")):
             yield
             return
         before = model.plan_batch
+        graph = bool(getattr(model, "_graph_replay", False))
         model.set_plan_batch((self.batch or self.default_batch()) if self.reproducible else 0)
+        if graph:
+            model.set_graph_replay(False)
         try:
             yield
         finally:
             model.set_plan_batch(before)
+            if graph:
+                model.set_graph_replay(True)
 
     # ---- the driver ------------------------------------------------------------------------------
     @torch.no_grad()

@@ -81,7 +81,8 @@ def main():
                       "batch": a.batch or E.default_batch(), "chunk": a.chunk, "io_threads": E.io_threads, "io_mode": a.io_mode,
                       "cpus": len(os.sched_getaffinity(0)), "cpu_budget": ev.cpu_budget(), "png_compress_level": a.compress,
                       "wall_s": wall, "wall_s_runs": [round(w, 4) for w in walls[1:]], "frames_per_s_end_to_end": n / wall,
-                      "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units", "timeline")},
+                      "phase_s_last_run": {k: round(v, 4) for k, v in tm.items() if k not in ("frames", "units", "timeline", "peak_units_in_flight")},
+                      "peak_units_in_flight": tm.get("peak_units_in_flight"),
                       "unit_timeline_s [decoded, enqueued, on host, written]": tm.get("timeline"),
                       "pipeline_units_last_run": tm.get("units")}))
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r04
+#   bash tools/refresh_profiles.sh r05
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -39,16 +39,34 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_I
 done
 echo "[refresh] other shapes and modes"
 rm -f $OUT/${TAG}_other_shapes.jsonl $OUT/${TAG}_other_shapes.err
-for flags in "--height 320 --width 480" "--height 320 --width 480 --no-tuning" "--height 320 --width 480 --dtype bf16" "--height 320 --width 480 --dtype bf16 --no-tuning" "--height 320 --width 480 --mode chain --frames 16 --batch 8" "--height 320 --width 480 --dtype bf16 --mode chain --frames 16 --batch 8" "--mode chain --frames 32" "--mode chain --frames 32 --batch 4" "--mode chain --frames 32 --batch 8" "--mode clips --frames 32" "--mode clips --frames 32 --graph" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype bf16 --mode chain --frames 32 --batch 4" "--dtype f16" "--dtype f16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
+for flags in "--height 320 --width 480" "--height 320 --width 480 --no-tuning" "--height 320 --width 480 --dtype bf16" "--height 320 --width 480 --dtype bf16 --no-tuning" "--height 320 --width 480 --mode chain --frames 16 --batch 8" "--height 320 --width 480 --dtype bf16 --mode chain --frames 16 --batch 8" "--mode chain --frames 32" "--mode chain --frames 32 --batch 4" "--mode chain --frames 32 --batch 8" "--mode chain --frames 32 --batch 3 --plan-batch 4" "--mode chain --frames 32 --batch 1 --plan-batch 4" "--height 320 --width 480 --mode chain --frames 16 --batch 3 --plan-batch 8" "--mode clips --frames 32" "--mode clips --frames 32 --graph" "--dtype bf16" "--dtype bf16 --mode chain --frames 32" "--dtype bf16 --mode chain --frames 32 --batch 4" "--dtype f16" "--dtype f16 --mode chain --frames 32" "--inflight 3" "--batch 2" "--batch 4" "--batch 8" "--size 1024 --batch 4" "--size 1024 --batch 4 --dtype bf16" "--size 1024" "--size 256"; do
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
 echo "[refresh] bf16 kernel stats (config 3)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --dtype bf16 --mode chain --frames 32 --steps 10 --warmup 2 > $OUT/${TAG}_bench_bf16_prof.log 2>&1
 cp $OUT/prof_bf16/bench_kernel_stats.csv $OUT/${TAG}_bench_bf16_kernel_stats.csv
-echo "[refresh] multi-rank rehearsal on one GPU (2 ranks share device 0, gloo instead of RCCL): BASELINE config 4 shape"
+echo "[refresh] multi-rank rehearsals on one GPU (the ranks share device 0, gloo instead of RCCL; at most 6 processes may use the card): BASELINE config 4 shape"
 cd $ROOT
 RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo python3 bench.py --gpus 2 --mode clips --steps 3 --warmup 1 2> $OUT/${TAG}_clips_2ranks_1gpu.err | grep '^{' > $OUT/${TAG}_clips_2ranks_1gpu.json      # (gloo prints its connection banner on stdout)
+# six ranks on the one GPU, launch by launch and as graph replays: replicas bit-equal, host-enqueue vs device time per rank
+# (the known-good reference log for the first real multi-GPU run; the card is time-shared, so the rates say nothing)
+rm -f $OUT/${TAG}_clips_6ranks_1gpu.jsonl
+for flags in "" "--graph"; do
+  echo "## bench.py --gpus 6 --mode clips --frames 16 $flags" >> $OUT/${TAG}_clips_6ranks_1gpu.jsonl
+  RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 6 --mode clips --frames 16 --steps 2 --warmup 1 $flags 2>> $OUT/${TAG}_clips_6ranks_1gpu.err | grep '^{' | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d['config']
+print(json.dumps({'value': d['value'], 'n_gpus': d['n_gpus'], 'replica_check': c['replica_check'], 'blob_checksum_equal_on_all_ranks': c['blob_checksum_equal_on_all_ranks'],
+                  'weight_broadcast_ms': c['weight_broadcast_ms'], 'per_rank_host_enqueue_ms_per_step': c['per_rank_host_enqueue_ms_per_step'],
+                  'per_rank_total_ms_per_step': c['per_rank_total_ms_per_step'], 'graph_replay': c['graph_replay'], 'per_rank_device': c['per_rank_device']}))" >> $OUT/${TAG}_clips_6ranks_1gpu.jsonl
+done
+echo "[refresh] the CLI with its default settings, 1 rank against 2 and 6 ranks sharing the GPU: the same bytes"
+rm -f $OUT/${TAG}_multirank_inference.jsonl
+for g in 2 6; do
+  RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo timeout -k 10 400 python3 tools/multirank_inference_check.py --gpus $g --keys 9 6 5 >> $OUT/${TAG}_multirank_inference.jsonl 2>> $OUT/${TAG}_multirank_inference.err
+done
+RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo timeout -k 10 400 python3 tools/multirank_inference_check.py --gpus 2 --keys 9 6 5 --no-reproducible >> $OUT/${TAG}_multirank_inference.jsonl 2>> $OUT/${TAG}_multirank_inference.err || true
 cd /tmp
 echo "[refresh] k_warp: timing + FETCH / WRITE counters"
 python3 $ROOT/tools/warp_bench.py --time --out $OUT/${TAG}_warp.json > $OUT/${TAG}_warp.log 2>&1
@@ -58,7 +76,7 @@ python3 $ROOT/tools/warp_bench.py --report $OUT/warp_f $OUT/warp_w --out $OUT/${
 rm -rf $OUT/warp_f $OUT/warp_w
 echo "[refresh] folder driver end to end (files in, files out)"
 rm -f $OUT/${TAG}_driver.jsonl
-for flags in "--size 512 --keys 5 --rate 32" "--size 512 --keys 3 --rate 32" "--size 512 --keys 5 --rate 32 --dtype bf16" "--size 512 --keys 5 --rate 32 --io-mode thread --batch 1 --lanes 3 --chunk 0 --io-threads 16" "--size 512 --keys 5 --rate 32 --compress 1" "--height 320 --width 480 --keys 9 --rate 16" "--height 320 --width 480 --keys 5 --rate 16" "--height 320 --width 480 --keys 9 --rate 16 --dtype bf16"; do
+for flags in "--size 512 --keys 5 --rate 32" "--size 512 --keys 5 --rate 32 --compress 1" "--height 320 --width 480 --keys 9 --rate 16" "--height 320 --width 480 --keys 9 --rate 16 --compress 1"; do
   echo "## $flags" >> $OUT/${TAG}_driver.jsonl
   timeout -k 10 300 python3 $ROOT/tools/driver_bench.py $flags >> $OUT/${TAG}_driver.jsonl 2>> $OUT/${TAG}_driver.err
 done
