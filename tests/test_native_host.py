@@ -297,4 +297,9 @@ def test_every_kernel_variant_of_the_library_is_used_by_some_plan(lib):
     from tools.variant_usage import usage
     info, used = usage()
     unused = [i for i, (prec, g) in enumerate(info) if i not in used and g[0] != 0]
-    assert len(unused) <= 4, [info[i] for i in unused]      # (a handful may fall out of use when a table is re-measured)
+    # (a handful fall out of use when a table is re-measured, and a candidate added for a tuning run is unused until a table picks it:
+    #  ADVICE r04 - a warning up to 16 entries, so that the autotuner's search space can be widened without editing this test)
+    if len(unused) > 4:
+        import warnings
+        warnings.warn("%d kernel variants of the library are launched by no plan of the sweep: %s" % (len(unused), [info[i] for i in unused][:6]))
+    assert len(unused) <= 16, [info[i] for i in unused]

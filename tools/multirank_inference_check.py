@@ -2,7 +2,7 @@
 """The product's multi-GPU path, end to end, on whatever GPUs the box has: writes a synthetic example folder
 (inputs / DAIN / Predict_motion, two clips) and a seed-defined checkpoint, runs `inference.py` once with one rank and once
 with N ranks (the CLI starts its own ranks; on a 1-GPU box set RIB_BENCH_DEVICE=0 RIB_DIST_BACKEND=gloo so that all ranks
-share the device - at most 6 there: the pool's process guard), with the CLI's DEFAULT settings (batched segments, batch-invariant
+share the device - at most 5 there: the pool's process guard allows 6 processes on the card and the launching process counts), with the CLI's DEFAULT settings (batched segments, batch-invariant
 plans), and compares the written PNGs byte for byte: an N-rank run must write exactly the files a 1-rank run writes.  This process never touches the GPU: the CLIs run as
 child processes.
 
