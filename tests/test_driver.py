@@ -234,6 +234,23 @@ def test_cubic_resize_follows_the_opencv_definition():
     assert 60 < pil.mean() < 110
 
 
+def test_cubic_resize_agrees_with_atens_bicubic_to_one_grey_level():
+    """A third-party anchor for the frame resize (cv2 itself is not in this image, so OpenCV's 8-bit INTER_CUBIC stays formally
+    unpinned): ATen's `upsample_bicubic2d` implements the same definition in float - Keys weights with A = -0.75, half-pixel
+    centres, replicated border, no low-pass on reduction (torch documents it as matching OpenCV's INTER_CUBIC) - so the 11-bit
+    fixed-point restatement must land within ONE grey level of it on every pixel and be identical on most, on enlargements,
+    reductions (1080p -> 512x512, 720p -> the reference's 320x480) and odd ratios."""
+    from render_in_between_amd import resize as rz
+    rng = np.random.default_rng(7)
+    for (h0, w0, h, w) in ((1080, 1920, 512, 512), (720, 1280, 320, 480), (256, 256, 512, 512), (300, 500, 320, 480), (64, 48, 32, 16), (37, 53, 80, 96)):
+        a = rng.integers(0, 256, size=(h0, w0, 3), dtype=np.uint8)
+        got = rz.resize_cubic_u8(a, w, h).astype(int)
+        t = torch.from_numpy(a.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = torch.nn.functional.interpolate(t, size=(h, w), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        d = np.abs(got - np.clip(np.rint(ref), 0, 255).astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.1, (h0, w0, h, w, int(d.max()), float((d > 0).mean()))
+
+
 def test_load_image_resizes_like_the_reference_transform(tmp_path):
     """`Evaluator.load_image` on a file that is not at the model size: the OpenCV-style cubic resize (default) equals the
     scalar restatement followed by ToTensor + Normalize(.5, .5); `resize="pil"` keeps PIL's bicubic; both report the
