@@ -127,6 +127,15 @@ class _ShmBlock:
         self.nbytes = int(nbytes)
         self.shm = shared_memory.SharedMemory(create=True, size=self.nbytes)
         self.name = self.shm.name
+        # tmpfs hands out pages on first touch, and a touch beyond what /dev/shm has left is a bus error in whichever process
+        # makes it (a decode worker, typically): reserve the pages now, so that exhaustion is an OSError here
+        try:
+            os.posix_fallocate(self.shm._fd, 0, self.nbytes)
+        except (AttributeError, OSError) as e:
+            if isinstance(e, OSError):
+                self.shm.close(); self.shm.unlink(); self.shm = None
+                raise MemoryError("Evaluator: /dev/shm cannot hold a %.1f MB staging block (%s); use io_mode='thread' or a larger /dev/shm"
+                                  % (self.nbytes / 1e6, e)) from e
         self.t = torch.from_numpy(np.ndarray((self.nbytes,), np.uint8, buffer=self.shm.buf))
         self.pinned = False
         if torch.cuda.is_available():
@@ -156,7 +165,12 @@ _SHM_FREE = {}          # nbytes -> [idle _ShmBlock]: blocks are reused across u
 _SHM_ALL = []
 
 
+_SHM_GRAIN = 1 << 20          # block sizes are rounded up to this: ragged groups / tail chunks then share a few size classes
+_SHM_KEEP = DECODE_AHEAD + MAX_UNITS_IN_FLIGHT + 4      # idle blocks kept per size class (the pipeline's windows); the rest is released
+
+
 def _shm_get(nbytes):
+    nbytes = (int(nbytes) + _SHM_GRAIN - 1) // _SHM_GRAIN * _SHM_GRAIN
     free = _SHM_FREE.get(nbytes)
     if free:
         return free.pop()
@@ -169,7 +183,12 @@ def _shm_get(nbytes):
 
 
 def _shm_put(blk):
-    _SHM_FREE.setdefault(blk.nbytes, []).append(blk)
+    free = _SHM_FREE.setdefault(blk.nbytes, [])
+    if len(free) >= _SHM_KEEP:
+        _SHM_ALL.remove(blk)
+        blk.close()
+    else:
+        free.append(blk)
 
 
 def _shm_close_all():
@@ -542,8 +561,9 @@ class Evaluator:
                         ui = opened[0]
                         gi, members, c0, c1 = units[ui]
                         if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
-                            stage_blk[ui] = _shm_get((c1 - c0) * len(members) * self.height * self.width * 3)
-                            stage[ui] = stage_blk[ui].t.view(c1 - c0, len(members), self.height, self.width, 3)
+                            nb = (c1 - c0) * len(members) * self.height * self.width * 3
+                            stage_blk[ui] = _shm_get(nb)              # (size classes of 1 MB: the block may be larger than the unit)
+                            stage[ui] = stage_blk[ui].t[:nb].view(c1 - c0, len(members), self.height, self.width, 3)
                         else:
                             stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
                         for b, si in enumerate(members):
@@ -600,7 +620,7 @@ class Evaluator:
                         prev_of[gi] = fz[-1]
                         q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
                         out_blk = _shm_get(q.numel()) if procs is not None else None       # shared with the encode workers, page-locked
-                        pinned = out_blk.t.view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                        pinned = out_blk.t[:q.numel()].view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
                         pinned.copy_(q, non_blocking=True)
                         done = torch.cuda.Event()
                         done.record(st)

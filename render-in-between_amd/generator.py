@@ -69,6 +69,7 @@ class Generator:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._plan_batch = 0
         self._tuned: Dict[tuple, int] = {}      # (B,H,W) -> launches whose variant came from the measured table
+        self._applied: Dict[tuple, int] = {}    # (TB,H,W) whose table entries have been pinned on the handle -> how many
         self.training = False
         self._graph_replay = bool(int(__import__("os").environ.get("RIB_GRAPH", "0") or 0))
         self.weights_version = 0        # bumped by load_state_dict / import_weights (Evaluator's lane clones follow it)
@@ -192,12 +193,15 @@ class Generator:
                 from . import tuning
                 if self._tuning is None:
                     self._tuning = tuning.load(dtype=self.compute_dtype)
-                self._tuned[key] = tuning.apply(self._lib, self._h, self._tuning, TB, H, W, dtype=self.compute_dtype)
+                if (TB, H, W) not in self._applied:      # once per followed shape: re-pinning drops the plans that follow it
+                    self._applied[(TB, H, W)] = tuning.apply(self._lib, self._h, self._tuning, TB, H, W, dtype=self.compute_dtype)
+                self._tuned[key] = self._applied[(TB, H, W)]
             n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0 and self._use_tuning and self._tuning.get("%d,%d,%d" % (TB, H, W)):
                 # a stale tuning entry must never break the path: drop it and use the cost model
                 for op in self._tuning["%d,%d,%d" % (TB, H, W)]:
                     self._lib.rib_set_choice(self._h, TB, H, W, op.encode(), -1, 1)
+                self._applied[(TB, H, W)] = self._tuned[key] = 0
                 n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0:
                 _native.check(self._h, -1)

@@ -317,7 +317,7 @@ def test_io_worker_processes_return_what_the_threads_compute(tmp_path):
     try:
         off = 32 * 48 * 3
         got = pool.submit(io_worker.load_frame_shm, blk.name, off, *args).result()
-        assert got[0] is None and np.array_equal(blk.t.numpy()[off:].reshape(32, 48, 3), want[0])
+        assert got[0] is None and np.array_equal(blk.t.numpy()[off:2 * off].reshape(32, 48, 3), want[0])
         assert np.array_equal(io_worker.normalised_chw(got[1]), want[1])
         assert all(np.array_equal(a, b) for a, b in zip(got[2], want[2]))
         shm_png = os.path.join(root, "s.png")
