@@ -200,6 +200,30 @@ def test_inference_cli_surface():
         mod.load_generator(cfg)
 
 
+def test_inference_cli_exposes_the_drivers_choices():
+    """the driver's real trade-offs are flags of the CLI, not constructor arguments - PNG level (default: the
+    reference's bytes), batch-invariant plans (default on), batch, dtype, ranks - and every rank ends with one summary line that
+    names frames, rate, the launch thread's phases, the in-flight window, workers and the CPU budget."""
+    import importlib.util
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "render-in-between_amd", "inference.py")
+    src = open(p).read()
+    for flag in ("--png-level", "--reproducible", "--batch", "--dtype", "--gpus"):
+        assert flag in src, flag
+    spec = importlib.util.spec_from_file_location("rib_inference2", p)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    from render_in_between_amd.evaluator import Evaluator
+    cfg = rib.AttrDict(gen=rib.hsm_gen_config(), model_height=320, model_width=480)
+    E = Evaluator(cfg)                                         # defaults: the reference's PNG bytes, batch-invariant plans
+    assert E.reproducible and E.png_compress_level is None and E.default_batch() == 8
+    E.timings = {"frames": 129, "wall": 0.6, "load": 0.02, "rasterise": 0.13, "generate": 0.01, "save": 0.43, "units": 8, "peak_units_in_flight": 8}
+    line = mod.summary_line(E, 1, 2)
+    for part in ("[rank 1/2]", "129 frames", "215.0 frames/s", "load 0.02 s", "save tail 0.43 s", "8 units, <= 8 in flight", "PNG level reference (zlib 6)", "batch 8", "batch-invariant plans"):
+        assert part in line, (part, line)
+    E2 = Evaluator(cfg, png_compress_level=1, reproducible=False, batch=2)
+    E2.timings = {"frames": 0}
+    assert "PNG level 1, batch 2, per-batch plans" in mod.summary_line(E2)
+
+
 def test_cubic_resize_follows_the_opencv_definition():
     """The folder driver's resize (render-in-between_amd/resize.py, vectorised) against the scalar restatement of
     OpenCV's 8-bit INTER_CUBIC in oracle/resize_ref.py (written independently): bit-exact on enlargements, reductions,
