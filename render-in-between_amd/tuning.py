@@ -18,7 +18,8 @@ PREC = {"f32": 0, "bf16": 1, "f16": 2}           # what rib_variant_info returns
 
 def load(path=None, dtype="f32"):
     if path is None:
-        path = TUNING_PATHS[dtype]
+        # RIB_TUNING_TABLE_<DTYPE>=<file>: another table for this process (A/B of two tables in one gpurun call)
+        path = os.environ.get("RIB_TUNING_TABLE_" + dtype.upper()) or TUNING_PATHS[dtype]
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
