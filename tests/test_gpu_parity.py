@@ -210,7 +210,7 @@ def test_warp_extension_matches_grid_sample():
     # torch.linspace by an ulp of 1, i.e. 1e-4 pixels at that width): white-noise image = the steepest gradients a [-1, 1] frame has,
     # smooth +-3 px flow (every tap in the staged window), +-40 px flow (every pixel on the global-load path), a width that is
     # not a multiple of 4 (element-wise staging / stores) and one that does not tile
-    for (B, H, W, amp, seed) in ((2, 1024, 1024, 3.0, 11), (1, 1024, 1024, 40.0, 12), (1, 510, 1022, 6.0, 13), (1, 250, 333, 9.0, 14)):
+    for (B, H, W, amp, seed) in ((2, 1024, 1024, 3.0, 11), (1, 1024, 1024, 40.0, 12), (2, 510, 1022, 6.0, 13), (1, 250, 333, 9.0, 14), (4, 250, 333, 50.0, 15)):
         g = torch.Generator().manual_seed(seed)
         img = torch.rand(B, 3, H, W, generator=g) * 2 - 1
         low = torch.randn(B, 2, max(1, H // 32), max(1, W // 32), generator=g)
