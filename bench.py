@@ -60,6 +60,13 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32",
                     help="f32 (default, the reference's arithmetic), bf16 (BASELINE configs[2]: bf16 storage) or f16 (the same "
                          "16-bit kernels with IEEE half elements); the 16-bit modes are separately reported, never the headline")
+    ap.add_argument("--products", choices=("f32", "bf16x3"), default="f32",
+                    help="fp32 mode only: f32 (default) = exact-fp32 matrix-core products everywhere, the reference's arithmetic; bf16x3 = "
+                         "the plain GEMMs of the frame form each product from six bf16 products of three-way split operands "
+                         "(rib_set_products; opt-in, named in config.workload, never the headline)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run only: skip the short measurements of BASELINE configs[2] (32-frame bf16 chain) and configs[4] "
+                         "(1024x1024 batch 4) that are attached to the line as other_configs")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frames in flight per GPU: each on its own HIP stream with its own handle and "
                          "workspace (segments between key frames are independent, SURVEY F9); every forward stays batch=B")
@@ -92,6 +99,50 @@ def clip_inputs(spec, synth, r, T, H, W):
     dains = torch.stack([f[1] for f in frames])           # [T,1,3,H,W]
     key = frames[0][2]                                    # the key frame the chain starts from
     return key, labels, dains
+
+
+def frame_bytes_model(B, H, W, dtype):
+    """Fused-minimum HBM bytes of one forward: 2.82 GB per 512x512 fp32 frame, 0.123 GB of it weights."""
+    px = B * H * W / (512.0 * 512.0)
+    return (2.694e9 * px + 0.123e9) * (0.5 if dtype != "f32" else 1.0)
+
+
+def measure_other_config(rib, synth, cfg, spec, sd, dev, name, dtype, products, mode, B, H, W, T, steps, warmup):
+    """One short measurement of another BASELINE configuration in this process, AFTER the headline's timed region:
+    its own Generator (own storage mode, own measured table), `warmup` untimed and `steps` timed steps between device
+    synchronisations.  Returns the entry of `other_configs`."""
+    G = rib.Generator(cfg, device=dev, compute_dtype=dtype, products=products).eval()
+    G.load_state_dict(sd)
+    label, fake, prev = [t.to(dev) for t in synth.make_inputs(spec, B, H, W, 0)]
+    if mode == "chain":
+        labels = label.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+        dains = fake.unsqueeze(0).repeat(T, 1, 1, 1, 1).contiguous()
+        step = lambda: G.chain(prev, labels, dains, want_all=False)[2]
+        frames = B * T
+    else:
+        step = lambda: G.forward_blend(label, None, fake, prev)[2]
+        frames = B
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    flops = sum(G.forward_flops(B, H, W).values()) * (frames / B)
+    byts = frame_bytes_model(B, H, W, dtype) * (frames / B)
+    t_mfma = flops / ((PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS) * 1e12)
+    t_hbm = byts / (PEAK_HBM_GBS * 1e9)
+    entry = {"name": name, "workload": None, "dtype": dtype, "products": products, "value": frames / dt, "unit": "frames/s",
+             "ms_per_step": dt * 1e3, "frames_per_step": frames, "steps": steps, "warmup": warmup,
+             "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac": max(t_mfma, t_hbm) / dt,
+             "frac_basis": "SURVEY 8(d) roof of the whole step: max(algorithmic FLOPs / dense MFMA peak of the dtype, fused-minimum bytes / 8 TB/s) / measured step time",
+             "launches_per_forward": G.num_launches(B, H, W),
+             "kernel_choices": "measured table" if G.tuned_ops(B, H, W) else "analytic cost model (no table for this shape)"}
+    del G, label, fake, prev
+    torch.cuda.empty_cache()
+    return entry
 
 
 def main():
@@ -127,7 +178,9 @@ def main():
     spec = rib.GenSpec.from_cfg(cfg)
     H, W = (args.height or args.size), (args.width or args.size)
     B = args.batch
-    G = rib.Generator(cfg, device=dev, compute_dtype=args.dtype, use_tuning=not args.no_tuning).eval()
+    if args.products != "f32" and args.dtype != "f32":
+        raise SystemExit("--products bf16x3 is an option of the fp32 mode")
+    G = rib.Generator(cfg, device=dev, compute_dtype=args.dtype, products=args.products, use_tuning=not args.no_tuning).eval()
     G.set_plan_batch(args.plan_batch)
     sd = None
     t_bcast_ms = 0.0
@@ -149,7 +202,7 @@ def main():
         blob = G.export_weights()
         torch.cuda.synchronize(dev)
         for _ in range(args.inflight - 1):
-            lanes.append((rib.Generator(cfg, device=dev, compute_dtype=args.dtype, use_tuning=not args.no_tuning).eval().set_plan_batch(args.plan_batch).import_weights(blob), torch.cuda.Stream(device=dev)))
+            lanes.append((rib.Generator(cfg, device=dev, compute_dtype=args.dtype, products=args.products, use_tuning=not args.no_tuning).eval().set_plan_batch(args.plan_batch).import_weights(blob), torch.cuda.Stream(device=dev)))
         torch.cuda.synchronize(dev)
 
     frames_per_step = B
@@ -244,7 +297,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    log("timed region done: %.3f ms/step" % ms_per_step)
+    log("timed region done: %d steps, %.3f ms/step" % (args.steps, ms_per_step))
     # ---- roofline of the dominant kernel class: profiling pass (not in the timed region) ----
     # Every launch of the pass carries a (start, stop) HIP event pair bound to the dispatch itself (hipExtLaunchKernelGGL,
     # rib_profile_begin_kernels): the difference is the kernel's own execution time on the launch stream - the duration
@@ -254,6 +307,7 @@ def main():
     flops = G.forward_flops(B, H, W)
     G.profile_begin(kernels=True)
     nprof = 20 if args.mode == "frame" else 1      # (5 steps gave the class time a run-to-run spread of +-3 %)
+    log("profile pass (separate from the timed region, after it): %d step(s) with an event pair on every dispatch" % nprof)
     for _ in range(nprof):
         step()
     prof = G.profile_collect()
@@ -324,8 +378,7 @@ def main():
     # fused-minimum HBM model of SURVEY 8(d) (every conv reads its input and writes its output once, one extra read per
     # normalised tensor, one cond read per SPADE layer, weights once): 2.82 GB per 512x512 fp32 frame, of which 0.123 GB
     # are weights; activations scale with the pixel count, bf16 storage halves everything
-    px = B * H * W / (512.0 * 512.0)
-    alg_bytes = (2.694e9 * px + 0.123e9) * (0.5 if args.dtype != "f32" else 1.0)
+    alg_bytes = frame_bytes_model(B, H, W, args.dtype)
     hbm_gbs = alg_bytes * (frames_per_step / B) / (ms_per_step * 1e-3) / 1e9
     # headline fraction: the live kernel-time figure, unless the committed rocprofv3 trace of this very build says less
     live_frac = conv_tflops / peak
@@ -408,7 +461,32 @@ def main():
                          "(cgroup quota) and 8 threads (SURVEY 8d); `value` / `cores` = the faster setting"
                          % (reps, H, W, B)}
 
+    # ---- the other single-GPU BASELINE configurations, measured briefly in the same process: the
+    # 32-frame bf16 chain (configs[2]) and one 1024x1024 batch-4 fp32 forward (configs[4]); plus the opt-in split-product
+    # setting on the headline workload, named as such.  Only beside the default command's line; never part of `value`.
+    others = None
+    if default_workload and world == 1 and args.products == "f32" and not args.no_other_configs and not args.no_tuning and args.inflight == 1:
+        others = []
+        if sd is None:
+            sd = synth.make_state_dict(spec, 0)
+        for (name, dtype, products, mode, oB, oS, oT, osteps, owarm) in (
+                ("BASELINE configs[2]", "bf16", "f32", "chain", 1, 512, 32, 4, 1),
+                ("BASELINE configs[4]", "f32", "f32", "frame", 4, 1024, 1, 5, 2),
+                ("BASELINE configs[1] with the opt-in split-bf16 products on the plain GEMMs (NOT the reference's arithmetic)", "f32", "bf16x3", "frame", 1, 512, 1, 100, 10)):
+            try:
+                e = measure_other_config(rib, synth, cfg, spec, sd, dev, name, dtype, products, mode, oB, oS, oS, oT, osteps, owarm)
+            except Exception as ex:      # an extra must never take the headline line down with it
+                e = {"name": name, "error": "%s: %s" % (type(ex).__name__, ex)}
+            else:
+                dn = {"f32": "fp32", "bf16": "bf16 storage", "f16": "half storage"}[dtype] + (", split-bf16 (bf16x3) products on the k_gemm_dma launches" if products != "f32" else "")
+                e["workload"] = ("%dx%d autoregressive %d-frame segment, batch=%d, %s" % (oS, oS, oT, oB, dn) if mode == "chain"
+                                 else "%dx%d single-frame generator fwd + blend, batch=%d, %s" % (oS, oS, oB, dn))
+            others.append(e)
+            log("other config %s: %s" % (name, {k: e.get(k) for k in ("value", "ms_per_step", "frac", "error") if k in e}))
+
     dt_name = {"f32": "fp32", "bf16": "bf16 storage", "f16": "half storage"}[args.dtype]
+    if args.products != "f32":
+        dt_name += ", split-bf16 (bf16x3) products on the k_gemm_dma launches (opt-in: NOT the reference's exact-fp32 arithmetic)"
     if args.mode == "frame":
         workload = "%dx%d single-frame generator fwd + blend, batch=%d, %s" % (H, W, B, dt_name)
     elif args.mode == "chain":
@@ -432,9 +510,9 @@ def main():
                    "distinct_devices": len({i.split(" pci ")[-1] for i in idents}),
                    "blob_checksum": sums[0], "blob_checksum_equal_on_all_ranks": len(set(sums)) == 1,
                    "replica_check": replica,
-                   "build": build["raw"], "height": H, "width": W, "plan_batch": args.plan_batch,
+                   "build": build["raw"], "height": H, "width": W, "plan_batch": args.plan_batch, "products": args.products,
                    "kernel_choices": "analytic cost model" if args.no_tuning else ("measured table" if G.tuned_ops(B, H, W) else "analytic cost model (no table for this shape)")},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_configs": others,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

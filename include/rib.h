@@ -109,6 +109,20 @@ int rib_import_weights(rib_handle* h, const void* src_device, size_t bytes, void
 enum { RIB_DTYPE_F32 = 0, RIB_DTYPE_BF16 = 1, RIB_DTYPE_F16 = 3 };   /* (2 was round 2's retired split-bf16 mode) */
 int rib_set_compute_dtype(rib_handle* h, int dtype);
 
+/* ---- arithmetic of the GEMM-shaped launches in RIB_DTYPE_F32 mode (no reference counterpart; OPT-IN, round 6).
+ *   RIB_PRODUCTS_F32 (default)  exact-fp32 matrix-core products everywhere: the reference's arithmetic, the mode every parity
+ *                               claim and the bench headline are made in.
+ *   RIB_PRODUCTS_BF16X3         the plain GEMMs of the frame (k_gemm_dma: the Winograd-domain GEMMs of the deep 3x3 layers and the
+ *                               gamma/beta GEMM of a condition level) split every fp32 operand value into three bf16 numbers
+ *                               (hi + mid + lo, exact) in registers and form a product from six bf16 matrix-core products
+ *                               accumulated in fp32 (dropped cross terms < 2^-24 |a b|).  Storage, layouts, the weight blob
+ *                               and every other kernel are unchanged.  Against an fp64 GEMM it is no less accurate than the
+ *                               exact-fp32 MFMA chain (rms error 0.4-0.9x: fewer roundings of the running sum), but it is
+ *                               not the reference's arithmetic: results differ from the default's by fp32 rounding noise.
+ * Takes effect at the next launch (plans and tuned choices are shared between the two); ignored by the 16-bit modes. ---- */
+enum { RIB_PRODUCTS_F32 = 0, RIB_PRODUCTS_BF16X3 = 1 };
+int rib_set_products(rib_handle* h, int products);
+
 /* ---- forward: replaces  img, mask = net_G(label, label_prev, img_fake, img_prev)
  *      (PGNR/models/generator.py:181-234; call site PGNR/models/evaluator.py:255) ----
  * label [B,label_nc,H,W], img_fake/img_prev [B,image_nc,H,W] -> img [B,image_nc,H,W] (tanh),

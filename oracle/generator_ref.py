@@ -118,9 +118,12 @@ def mask_res_block(sd, name, x):
 class RefGenerator:
     """Restatement of Generator (PGNR/models/generator.py:35-302)."""
 
-    def __init__(self, spec, state_dict):
+    def __init__(self, spec, state_dict, dtype=torch.float32):
+        """dtype=torch.float64: the same restatement evaluated in double precision (inputs are converted on entry) - the
+        yardstick fp32 implementations are ranked against (tools/products_error.py, tests/test_precision_model.py)."""
         self.spec = spec
-        self.sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
+        self.dtype = dtype
+        self.sd = {k: v.detach().to(dtype) for k, v in state_dict.items()}
 
     # LabelEmbedder.forward, arch 'encoder' (generator.py:360-387)
     def embed(self, x):
@@ -162,6 +165,7 @@ class RefGenerator:
     @torch.no_grad()
     def forward(self, label, label_prev, img_fake, img_prev, taps: Optional[dict] = None):
         sp, sd = self.spec, self.sd
+        label, img_fake, img_prev = label.to(self.dtype), img_fake.to(self.dtype), img_prev.to(self.dtype)
         cond = self.embed(torch.cat([img_fake, img_prev], dim=1))            # :197
         if taps is not None:
             for i, c in enumerate(cond):

@@ -44,6 +44,7 @@ SIGNATURES = {
     "rib_export_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rib_import_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rib_set_compute_dtype": (C.c_int, [C.c_void_p, C.c_int]),
+    "rib_set_products": (C.c_int, [C.c_void_p, C.c_int]),
     "rib_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rib_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
                     + [C.c_size_t, C.c_void_p]),

@@ -36,9 +36,36 @@ struct GemmDmaParams {
 // ST = ST_BF16 / ST_F16: A and B hold 16-bit elements (lda, K, sA, sB in elements), a 128-byte row chunk is 64 of them, a
 // lane's 16-byte slot feeds ONE v_mfma_f32_32x32x16 (k = 8 per lane half) where it feeds four fp32 MFMAs; C stays fp32 (the
 // level slab k_spade_modulate reads).  Same tile, same swizzle, same two stages.
-template <int WM, int WN, int NF, int ST = ST_F32>
+//
+// X3 (round 6, rib_set_products(RIB_PRODUCTS_BF16X3), OPT-IN, fp32 storage only): the same fp32 tiles, but every operand value
+// is split after its ds_read into hi + mid + lo - three bf16 numbers by truncation, the two subtractions are exact - and a
+// product becomes six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl, lh, mm; the dropped terms ml, lm, ll are below 2^-24 |a b|)
+// accumulated in fp32: 3/8 of the matrix-pipe time of the exact-fp32 MFMAs, paid for with 11 vector instructions per pair of
+// values.  X3 = 2 keeps the hh products in an accumulator of their own, so the five small terms never round against the large
+// sum.  Against an fp64 GEMM the rms error is 0.87 (X3 = 1) / 0.38 (X3 = 2) of the exact-fp32 MFMA chain's (one rounding
+// per MFMA instead of one per product); tools/probes/gemm_x3_probe.hip, profiles/r06_gemm_x3_probe.txt.  It is NOT the
+// reference's arithmetic, hence never the default and always named in bench.py's workload string.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_bf16(const float4 p, const float4 q, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
+    h[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // the high halves of two words = two truncated bf16 values
+    const float r0 = x[2 * i] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+  hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int WM, int WN, int NF, int ST = ST_F32, int X3 = 0>
 __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(X3 == 0 || ST == ST_F32, "split products: fp32 storage");
   constexpr int BM = 32 * WM, BN = 32 * NF * WN, BK = 32;      // BK: 4-byte words of a row chunk (128 bytes)
   constexpr int EPW = ST == ST_F32 ? 1 : 2;                    // elements per 4-byte word
   constexpr int STAGE = (BM + BN) * BK;              // floats
@@ -53,10 +80,11 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
   const float* A = p.A + (size_t)z * p.sA / EPW;
   const float* B = p.B + (size_t)(p.modB ? z % p.modB : 0) * p.sB / EPW;
   f32x16 acc[NF];
+  f32x16 acc_s[X3 == 2 ? NF : 1];      // X3 = 2: the five small product terms
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[nf][r] = 0.f; if constexpr (X3 == 2) acc_s[nf][r] = 0.f; }
   const int nch = p.K / (BK * EPW);
   typedef __attribute__((address_space(3))) void lds_void;
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
@@ -86,6 +114,32 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
     if (c + 1 < nch) fill(st ^ 1, (c + 1) * BK);
     const float* sA = smem + st * STAGE;
     const float* sB = sA + BM * BK;
+    if constexpr (X3 != 0) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        // this lane's 8 k values of the 16-channel step: slots 4 ks + lh and 4 ks + 2 + lh (which 8 does not matter: A and B agree)
+        const int s0 = ks * 4 + lh, s1 = s0 + 2;
+        const int ra = wm * 32 + li;
+        bf16x8 ah, am, al;
+        split3_bf16(*reinterpret_cast<const float4*>(sA + ra * BK + (s0 ^ ((ra >> 1) & 7)) * 4),
+                    *reinterpret_cast<const float4*>(sA + ra * BK + (s1 ^ ((ra >> 1) & 7)) * 4), ah, am, al);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int rb = (wn * NF + nf) * 32 + li;
+          bf16x8 bh, bm, bl;
+          split3_bf16(*reinterpret_cast<const float4*>(sB + rb * BK + (s0 ^ ((rb >> 1) & 7)) * 4),
+                      *reinterpret_cast<const float4*>(sB + rb * BK + (s1 ^ ((rb >> 1) & 7)) * 4), bh, bm, bl);
+          f32x16& sm = X3 == 2 ? acc_s[nf] : acc[nf];      // small terms first
+          sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, sm, 0, 0, 0);
+          sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, sm, 0, 0, 0);
+          sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, sm, 0, 0, 0);
+          sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, sm, 0, 0, 0);
+          sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, sm, 0, 0, 0);
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nf], 0, 0, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       const int slot = kb * 2 + lh;
@@ -120,7 +174,9 @@ __global__ __launch_bounds__(256) void k_gemm_dma(const GemmDmaParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < p.M && col < p.N) C[(size_t)row * p.ldc + col] = acc[nf][r];
+      float v = acc[nf][r];
+      if constexpr (X3 == 2) v += acc_s[nf][r];
+      if (row < p.M && col < p.N) C[(size_t)row * p.ldc + col] = v;
     }
   }
 }

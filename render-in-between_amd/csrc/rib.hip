@@ -269,6 +269,7 @@ struct Variant {
                                // the lean one); no fused-shortcut instantiation; reported as TB = 100 in the exported geometry
   typedef void (*GemmDmaFn)(const GemmDmaParams);
   GemmDmaFn gfn = nullptr;
+  GemmDmaFn gfn_x3 = nullptr;  // the same tile with split-bf16 products (rib_set_products(RIB_PRODUCTS_BF16X3); fp32 storage only)
   bool dma() const { return FRW == 0; }
   int BM() const { return 32 * WM; }
   int TH() const { return (32 / FRW) * MF * WM; }
@@ -375,17 +376,21 @@ inline IgemmFn pick_igemm_fn(const Variant* v, const IgemmParams& p) {
 }
 
 inline Variant dmak_variant(Variant v) { v.DMAK = 1; return v; }
-inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn, int prec = PREC_F32) {
+inline Variant dma_variant(int WM, int WN, int NF, Variant::GemmDmaFn fn, int prec = PREC_F32, Variant::GemmDmaFn fn_x3 = nullptr) {
   Variant v{0, WM, WN, 1, NF, prec == PREC_F32 ? 32 : 64, 1, 1, false, false, nullptr};      // BK: elements of a 128-byte row chunk
   v.gfn = fn;
+  v.gfn_x3 = fn_x3;
   v.BF16 = prec;
   return v;
 }
+// split-bf16 twin of an fp32 tile: the hh products in their own accumulator where the registers allow it (NF <= 2)
+#define RIB_DMA_X3(WM, WN, NF) PREC_F32, &k_gemm_dma<WM, WN, NF, ST_F32, (NF <= 2 ? 2 : 1)>
 const Variant kVariants[] = {
 #include "variants.def"
     // k_gemm_dma tiles (instantiated in this translation unit): 128x64, 64x64, 64x128, 128x128, 128x32
-    dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2>), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1>), dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2>),
-    dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4>), dma_variant(4, 1, 1, &k_gemm_dma<4, 1, 1>),
+    dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2>, RIB_DMA_X3(4, 1, 2)), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1>, RIB_DMA_X3(2, 2, 1)),
+    dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2>, RIB_DMA_X3(2, 2, 2)), dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4>, RIB_DMA_X3(4, 1, 4)),
+    dma_variant(4, 1, 1, &k_gemm_dma<4, 1, 1>, RIB_DMA_X3(4, 1, 1)),
     // ... and their 16-bit storage twins (the condition-level GEMMs of the bf16 / half modes)
     dma_variant(4, 1, 2, &k_gemm_dma<4, 1, 2, ST_BF16>, PREC_BF16), dma_variant(2, 2, 1, &k_gemm_dma<2, 2, 1, ST_BF16>, PREC_BF16),
     dma_variant(2, 2, 2, &k_gemm_dma<2, 2, 2, ST_BF16>, PREC_BF16), dma_variant(4, 1, 4, &k_gemm_dma<4, 1, 4, ST_BF16>, PREC_BF16),
@@ -613,6 +618,7 @@ struct rib_handle {
   bool weights_ready = false;
   int prec_mode = PREC_F32;    // rib_set_compute_dtype: PREC_BF16 / PREC_F16 = 16-bit storage + 16-bit matrix-core operands
   int prec() const { return prec_mode; }
+  int products = 0;            // rib_set_products: RIB_PRODUCTS_BF16X3 = the k_gemm_dma launches of the fp32 mode run their split-bf16 twins
   bool mc16() const { return prec_mode != PREC_F32; }                    // the matrix-core kernels read 16-bit filter copies, 16-channel steps
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
   int esz() const { return mc16() ? 2 : 4; }                       // bytes per stored activation element
@@ -2154,7 +2160,7 @@ int run_plan(rib_handle* h, Plan* P, const Resolver& R, hipStream_t st, bool ski
       case OP_GEMM: {
         GemmDmaParams p = op.gp;
         p.A = R.get<const float>(op.g_a); p.B = R.get<const float>(op.g_b); p.C = R.get<float>(op.g_c);
-        RIB_KLAUNCH(op.var->gfn, op.grid, dim3(256), 0, st, p);
+        RIB_KLAUNCH(h->products == RIB_PRODUCTS_BF16X3 && op.var->gfn_x3 ? op.var->gfn_x3 : op.var->gfn, op.grid, dim3(256), 0, st, p);
       } break;
       case OP_FINALIZE: {
         FinalizeParams p = op.fp;
@@ -2545,6 +2551,14 @@ int rib_set_compute_dtype(rib_handle* h, int dtype) {
     for (auto& t : h->tensors) all = all && t.set && (!t.used || !t.data.empty());
     if (all) return rib_finalize_weights(h);
   }
+  return RIB_OK;
+}
+
+int rib_set_products(rib_handle* h, int products) {
+  if (!h || (products != RIB_PRODUCTS_F32 && products != RIB_PRODUCTS_BF16X3)) return RIB_ERR_INVALID;
+  if (h->products == products) return RIB_OK;
+  drop_chain_graphs(h);      // (captured segments hold the kernels of the other setting)
+  h->products = products;
   return RIB_OK;
 }
 
@@ -2958,11 +2972,8 @@ int rib_debug_spade_weight(rib_handle* h, const char* conv_name, float* w_2c_by_
 }
 
 // Launch list of a plan, for the CPU-side structure tests: "<name>|<kernel class>|<grid>|<tile>"
-int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf, size_t buflen) {
-  if (!h || !buf) return RIB_ERR_INVALID;
-  Plan* P = get_plan(h, B, H, W);
-  if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
-  const Op& op = P->ops[idx];
+namespace {
+int rib_debug_launch_info_head(const Op& op, char* buf, size_t buflen) {
   if (op.kind == OP_IGEMM && op.small_co > 0)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|%s 16x16 tile, %d output channels%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
@@ -2979,6 +2990,84 @@ int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf
   else
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;
+}
+}  // namespace
+
+namespace {
+// Algorithmic HBM bytes of one launch (tools/prof_ops.py prices every launch against max(FLOPs / MFMA peak, these bytes / HBM)):
+// every operand the launch NEEDS read once, every result written once - activations in the storage type, filters and
+// statistics as stored; halo re-reads, split-K re-reads and L2 misses are exactly what this leaves out.
+double op_algorithmic_bytes(const rib_handle* h, const Plan* P, const Op& op) {
+  const double e = h->esz(), Bn = P->B;
+  switch (op.kind) {
+    case OP_IGEMM: {
+      const IgemmParams& p = op.ip;
+      const double samples = op.ip.pair ? 2.0 * Bn : Bn;      // a paired launch carries two convolutions per image
+      const int taps = op.var ? op.var->KS * op.var->KS : 9;
+      double b = samples * p.Hin * p.Win * (double)p.Cin * e                         // input (or SPADE condition map)
+                 + (double)p.CoutPad * taps * p.Cin * e * (op.ip.pair ? 2.0 : 1.0)   // filters
+                 + p.CoutPad * 4.0;                                                    // bias
+      if (op.var && op.var->SPADE) {
+        b += Bn * p.Hout * p.Wout * (double)p.C * e / (p.xm_ups ? 4.0 : 1.0);          // tensor being normalised
+        b += Bn * p.Hout * p.Wout * (double)p.C * e * p.nsets;                         // modulated outputs
+      } else if (p.slab) {
+        b += (double)p.ksplit * samples * p.Hout * p.Wout * p.CoutPad * 4.0;           // split-K partial slabs (fp32)
+      } else {
+        b += samples * p.Hout * p.Wout * (double)p.Cout * (op.small_co > 0 || p.y_f32 ? 4.0 : e);
+        if (p.res) b += samples * p.Hout * p.Wout * (double)p.Cout * e / (p.res_ups ? 4.0 : 1.0);
+        if (p.x2) b += samples * p.Hout * p.Wout * (double)p.Cin2 * e + (double)p.CoutPad * p.Cin2 * e;
+        if (p.bl_fuse) b += Bn * p.Hout * p.Wout * 3.0 * 4.0 * 3.0;                     // blend: img + dain read, fuse written (fp32 NCHW)
+      }
+      return b;
+    }
+    case OP_GEMM: {
+      const GemmDmaParams& g = op.gp;
+      const double Z = op.grid.z;
+      return Z * g.M * (double)g.K * e + (g.modB ? (double)g.modB : 1.0) * g.N * (double)g.K * e + Z * g.M * (double)g.N * 4.0;
+    }
+    case OP_LOWC: {
+      const LowcParams& l = op.lc;
+      return Bn * l.H * l.W * (double)(l.c0 + l.c1 + l.c2) * 4.0 + Bn * l.H * l.W * (double)l.Cout * e + 9.0 * (l.c0 + l.c1 + l.c2) * l.Cout * 4.0;
+    }
+    case OP_POOL: return Bn * op.pp.H * op.pp.W * (double)op.pp.C * e * 1.25;
+    case OP_INADD: return Bn * op.ap.HW * (double)op.ap.C * e * 3.0;
+    case OP_SPLITEPI: {
+      const SplitEpiParams& q = op.sp;
+      return (double)q.ksplit * q.B * q.Hout * q.Wout * q.CoutPad * 4.0 + (double)q.B * q.Hout * q.Wout * q.Cout * e * (q.res ? 2.0 : 1.0);
+    }
+    case OP_MODULATE: {
+      const ModulateParams& m = op.mp;
+      const double px = (double)m.B * m.Hout * m.Wout;
+      return px * 2.0 * m.C * m.nsets * 4.0 * m.ksplit + px * m.C * e / (m.xm_ups ? 4.0 : 1.0) + px * m.C * e * m.nsets;
+    }
+    case OP_WINO_IN: {
+      const WinoInParams& w = op.wi;
+      const int T = op.wino_m + 2;
+      double b = Bn * w.H * w.W * (double)w.Cin * e / (w.x_ups ? 4.0 : 1.0) + Bn * w.tilesY * w.tilesX * (double)T * T * w.Cin * e;
+      if (op.wi_mode != 0 && w.slab) b += Bn * w.H * w.W * 2.0 * w.Cin * 4.0;          // gamma/beta columns of the level slab
+      if (w.x2 || w.xres) b += Bn * w.H * w.W * (double)w.Cin * e * 2.0;               // join: second operand read, join stored
+      return b;
+    }
+    case OP_WINO_OUT: {
+      const WinoOutParams& w = op.wo;
+      const int T = op.wino_m + 2;
+      return Bn * w.tilesY * w.tilesX * (double)T * T * w.CoutPad * 4.0 + Bn * w.Hout * w.Wout * (double)w.Cout * e * (w.res ? 2.0 : 1.0);
+    }
+    case OP_FINALIZE: return Bn * op.fp.tiles * 2.0 * op.fp.Cs * 8.0;
+    default: return 0.0;
+  }
+}
+}  // namespace
+
+int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf, size_t buflen) {
+  if (!h || !buf) return RIB_ERR_INVALID;
+  Plan* P = get_plan(h, B, H, W);
+  if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
+  const Op& op = P->ops[idx];
+  const int rc = rib_debug_launch_info_head(op, buf, buflen);
+  const size_t n = strlen(buf);
+  if (n + 24 < buflen) snprintf(buf + n, buflen - n, "|%.0f", op_algorithmic_bytes(h, P, op));
+  return rc;
 }
 
 // ---- tuning hooks: enumerate kernel variants, pin a (variant, split-K) choice for one op of one

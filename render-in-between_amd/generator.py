@@ -28,13 +28,21 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Generator:
-    def __init__(self, gen_cfg, device=None, use_tuning=True, compute_dtype="f32"):
+    def __init__(self, gen_cfg, device=None, use_tuning=True, compute_dtype="f32", products="f32"):
         """compute_dtype: 'f32' (exact-fp32 matrix cores; the reference's arithmetic), 'bf16' (bf16 storage and
         matrix-core operands, fp32 accumulate / statistics; BASELINE config 3) or 'f16' (the same 16-bit kernels
-        with IEEE half elements: ~10x closer to fp32 than bf16 at the same speed)."""
+        with IEEE half elements: ~10x closer to fp32 than bf16 at the same speed).
+        products (fp32 mode only, opt-in): 'f32' = exact-fp32 products everywhere (default); 'bf16x3' = the plain GEMMs of
+        the frame form every product from six bf16 matrix-core products of three-way split operands (include/rib.h,
+        rib_set_products): fp32-grade, not the reference's arithmetic."""
         if compute_dtype not in ("f32", "bf16", "f16"):
             raise ValueError("compute_dtype must be 'f32', 'bf16' or 'f16'")
+        if products not in ("f32", "bf16x3"):
+            raise ValueError("products must be 'f32' or 'bf16x3'")
+        if products != "f32" and compute_dtype != "f32":
+            raise ValueError("products='bf16x3' is an option of the fp32 mode")
         self.compute_dtype = compute_dtype
+        self.products = products
         self.spec = GenSpec.from_cfg(gen_cfg)
         self._tuning = None
         self._use_tuning = use_tuning
@@ -66,6 +74,7 @@ class Generator:
                 *(("rib_create: " + msg.decode(),) if rc == -2 else (rc, msg.decode())))
         self._h = h
         _native.check(h, self._lib.rib_set_compute_dtype(h, {"f32": 0, "bf16": 1, "f16": 3}[compute_dtype]))
+        _native.check(h, self._lib.rib_set_products(h, {"f32": 0, "bf16x3": 1}[products]))
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._plan_batch = 0
         self._tuned: Dict[tuple, int] = {}      # (B,H,W) -> launches whose variant came from the measured table
@@ -147,7 +156,8 @@ class Generator:
         """A second handle on the same device with the same folded weights (device-to-device copy
         of the blob): used to keep several independent segments in flight on separate HIP streams
         (a handle is single-stream)."""
-        g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning, compute_dtype=self.compute_dtype)
+        g = Generator(self.gen_cfg, device=self.device, use_tuning=self._use_tuning, compute_dtype=self.compute_dtype,
+                      products=self.products)
         g.set_plan_batch(self._plan_batch)
         blob = self.export_weights()
         g.import_weights(blob)
@@ -416,6 +426,6 @@ class Generator:
         out = []
         for i in range(self._lib.rib_num_launches(self._h, B, H, W)):
             _native.check(self._h, self._lib.rib_debug_launch_info(self._h, B, H, W, i, buf, 512))
-            name, kclass, grid, tile, flops = buf.value.decode().split("|")
-            out.append({"name": name, "class": int(kclass), "grid": grid, "tile": tile, "flops": float(flops)})
+            name, kclass, grid, tile, flops, nbytes = buf.value.decode().split("|")
+            out.append({"name": name, "class": int(kclass), "grid": grid, "tile": tile, "flops": float(flops), "bytes": float(nbytes)})
         return out

@@ -1137,6 +1137,30 @@ def test_every_gemm_dma_tile_computes_the_same_frame():
         assert len(seen) == 5, seen
 
 
+def test_split_bf16_products_are_opt_in_and_fp32_grade():
+    """rib_set_products(RIB_PRODUCTS_BF16X3) (round 6): the k_gemm_dma launches form each fp32 product from six bf16 matrix-core
+    products of three-way split operands.  Off by default; when on, the frame differs from the default's by fp32 rounding
+    noise only and holds the same 2e-4 against the oracle (tools/products_error.py ranks the two against an fp64 oracle)."""
+    spec, sd, G0 = build("full", 0)
+    assert G0.products == "f32"
+    G1 = rib.Generator(rib.hsm_gen_config(), products="bf16x3").eval()
+    G1.load_state_dict(sd)
+    for (B, H, W) in ((1, 256, 256), (2, 80, 112)):
+        label, fake, prev = synth.make_inputs(spec, B, H, W, 41)
+        assert any("gemm (LDS-DMA" in x["tile"] for x in G1.launch_info(B, H, W))
+        i0, m0 = [t.clone() for t in G0(label, None, fake, prev)]
+        i1, m1 = G1(label, None, fake, prev)
+        assert not torch.equal(i0, i1)                     # other instructions ran ...
+        d = (float((i1 - i0).abs().max()), float((m1 - m0).abs().max()))
+        assert d[0] <= 5e-5 and d[1] <= 5e-5, (B, H, W, d)     # ... and moved nothing beyond fp32 rounding noise
+        oi, om = oracle(spec, sd)(label, None, fake, prev)
+        assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL
+    i2, _ = G1(label, None, fake, prev)
+    assert torch.equal(i1, i2)                             # deterministic
+    with pytest.raises(ValueError):
+        rib.Generator(rib.hsm_gen_config(), compute_dtype="bf16", products="bf16x3")
+
+
 def test_sixteen_channel_spade_layout_agrees_with_the_pair_layout(monkeypatch):
     """down_0.1 / up_0.1 modulate 16 channels: by default one [gamma(16) | beta(16)] MFMA fragment per wave (k_igemm<SPADE,
     NF = 1>, the halves exchange rows with shuffles); with RIB_NO_SPADE16 the pair layout every other SPADE uses.  Same

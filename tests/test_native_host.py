@@ -227,7 +227,7 @@ def test_plan_flops_and_shape_rules(lib):
     names = []
     for i in range(n):
         assert lib.rib_debug_launch_info(h, 1, 512, 512, i, buf, 512) == 0
-        name, kclass, grid, _, _ = buf.value.decode().split("|")
+        name, kclass, grid, _, _, _ = buf.value.decode().split("|")
         assert all(int(g) > 0 for g in grid.split(","))
         names.append(name)
     # (the deep 3x3 layers run in the Winograd domain at this size: transform, batched GEMM, transform)

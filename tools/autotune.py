@@ -61,7 +61,7 @@ def main():
         ops = []
         for i in range(lib.rib_num_launches(h, B, H, W)):
             lib.rib_debug_launch_info(h, B, H, W, i, buf, 512)
-            name, kclass, grid, tile, flops = buf.value.decode().split("|")
+            name, kclass, grid, tile, flops, _ = buf.value.decode().split("|")
             if tile.startswith("lowc"):
                 continue            # k_conv_lowc has one implementation per layer shape: nothing to choose
             if int(kclass) in (0, 1) and (args.only is None or args.only in name):
