@@ -243,7 +243,12 @@ int rib_time_op(rib_handle* h, int B, int H, int W, const char* op_name, const f
  * path); calls with other tensors capture their own graph (at most 8 are kept, least recently used first out).
  * Same kernels, parameters and order: frames are bit-identical to the launch-by-launch path (tested).  Meant for hosts
  * that drive many GPUs from few cores, where enqueueing ~130 launches per frame per GPU becomes the limiter.
- * rib_graph_stats: how many calls captured / replayed since rib_create. ---- */
+ * rib_graph_stats: how many calls captured / replayed since rib_create.
+ * A captured segment holds the plans' kernels and parameters, so every call that changes them - rib_set_choice,
+ * rib_set_plan_batch, rib_set_products, rib_set_compute_dtype, rib_set_debug_taps, rib_finalize_weights / rib_import_weights,
+ * turning replay off - destroys the handle's captured graphs first, and so does the eviction of the least recently used one:
+ * these calls BLOCK the host until the handle's device is idle (hipDeviceSynchronize: a graph may still be running on any
+ * stream it was replayed on) whenever captured graphs exist.  With no captured graph they do not synchronise. ---- */
 int rib_set_graph_replay(rib_handle* h, int enable);
 int rib_graph_stats(rib_handle* h, int64_t* captures, int64_t* replays);
 

@@ -622,6 +622,7 @@ struct rib_handle {
   bool mc16() const { return prec_mode != PREC_F32; }                    // the matrix-core kernels read 16-bit filter copies, 16-channel steps
   int padc(int c) const { return mc16() ? pad16(c) : pad8(c); }          // channel padding of an activation
   int esz() const { return mc16() ? 2 : 4; }                       // bytes per stored activation element
+  bool warp_lds_ready = false; // rib_warp has raised k_warp's dynamic-LDS limit on this handle's device
   bool keep_taps = false;      // rib_set_debug_taps: intermediate activations stay intact until the end of a forward
   // rib_set_plan_batch: > 0 = every launch plan, whatever its batch, follows the kernel choices (tuned table / cost model, split-K,
   // Winograd tile, fused or level-wise SPADE) of THIS batch size, so that a sample's arithmetic does not depend on how many other
@@ -666,10 +667,16 @@ namespace {
 // an instantiated graph may still be queued or running on the stream of its last launch (the launch only enqueues): that stream
 // is drained before the executable goes away (evictions and plan changes are rare; a replay never comes here)
 void destroy_chain_graph(rib_handle::ChainGraph& g) {
-  if (g.stream) (void)hipStreamSynchronize(g.stream);
+  // The graph may have been replayed on several streams (the key does not hold the stream) and a stream of an earlier replay may
+  // be gone by now: wait for the whole device instead of for the last stream alone.  Evictions and plan changes are rare; a
+  // replay never comes here.  (rib_set_choice / rib_set_plan_batch / rib_set_products therefore BLOCK the host when the handle
+  // holds captured segments: include/rib.h says so.)
+  (void)hipDeviceSynchronize();
   (void)hipGraphExecDestroy(g.exec);
 }
 void drop_chain_graphs(rib_handle* h) {
+  if (h->chain_graphs.empty()) return;
+  if (h->device >= 0) (void)hipSetDevice(h->device);      // (the device-wide wait below must be this handle's device)
   for (auto& g : h->chain_graphs) destroy_chain_graph(g);
   h->chain_graphs.clear();
 }
@@ -2631,8 +2638,13 @@ int rib_warp(rib_handle* h, int B, int C, int H, int W, const float* img, const 
   if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1) return fail(h, RIB_ERR_INVALID, "rib_warp: 1 <= C <= 8 channels (the staged window must fit in LDS)");
   const int tilesX = (W + WARP_TW - 1) / WARP_TW, tilesY = (H + WARP_TH - 1) / WARP_TH;
   const size_t lds = (size_t)C * WARP_WH * WARP_PITCH * sizeof(float);      // 16 KB per channel
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WARP_WH * WARP_PITCH * (int)sizeof(float));
-  if (attr != hipSuccess) return fail(h, RIB_ERR_HIP, fmt("rib_warp: %s", hipGetErrorString(attr)));
+  // k_warp's dynamic-LDS limit is raised once per HANDLE, with the handle's device current (the attribute may be kept per
+  // device: a process that drives two GPUs must not leave the second one at the 64 KB default), and a failure is reported
+  // by the call that met it, not cached for the life of the process
+  if (!h->warp_lds_ready) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_warp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WARP_WH * WARP_PITCH * (int)sizeof(float)));
+    h->warp_lds_ready = true;
+  }
   RIB_KLAUNCH(k_warp, dim3(tilesX * tilesY, B), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), img, flow, out, C, H, W, tilesX, xcd_chunk_of(tilesX * tilesY));
   HIP_TRY(h, hipGetLastError());
   return RIB_OK;

@@ -183,12 +183,21 @@ def _shm_get(nbytes):
 
 
 def _shm_put(blk):
-    free = _SHM_FREE.setdefault(blk.nbytes, [])
-    if len(free) >= _SHM_KEEP:
-        _SHM_ALL.remove(blk)
-        blk.close()
-    else:
-        free.append(blk)
+    """Back to the free list.  Nothing is unmapped here: while a call is running, tensor views of the block may still be
+    referenced (a unit's staging dict, the default arguments of a finisher that is still on the stack), and closing the
+    mapping under them turns a later access into a segfault instead of an exception.  Surplus blocks are
+    released by _shm_trim() at the end of evaluate_from_folder, when no unit is alive."""
+    _SHM_FREE.setdefault(blk.nbytes, []).append(blk)
+
+
+def _shm_trim():
+    """Release the idle blocks beyond _SHM_KEEP per size class (unregister, unmap, unlink).  Worker processes drop their own
+    attachment of an unlinked block the next time they attach a new one (io_worker._attach)."""
+    for free in _SHM_FREE.values():
+        while len(free) > _SHM_KEEP:
+            blk = free.pop()
+            _SHM_ALL.remove(blk)
+            blk.close()
 
 
 def _shm_close_all():
@@ -420,12 +429,9 @@ class Evaluator:
                              rank=None, world=None):
         """rank / world: this process's share of the independent units (default: the torch.distributed process
         group when one is initialised, else everything).  Returns the frames THIS rank wrote.
-        Pipelined over segments: file decode (thread pool) -> label rasterisation + autoregressive chain +
-        quantise on a lane's stream -> one pinned device-to-host copy per segment -> PNG encode (thread pool).
-        The main thread only enqueues; decode of later frames and encode of finished segments overlap the
-        GPU work (run back to back, the three phases cost about the same: 0.21 / 0.24 / 0.23 s for a
-        65-frame 512x512 clip, profiles/r01_raster_driver.json)."""
-        from PIL import Image
+        The call is one `_FolderPipeline` (below): plan a clip -> decode -> upload -> render -> sink, pipelined over units
+        of `chunk` x B frames; the launch thread only enqueues, decode of later units and encode of finished ones overlap
+        the GPU work."""
         if gen_vid:
             # the reference also writes <save_dir>/<clip>.mp4 (evaluator.py:267-269, utils.make_video); not built, and
             # silently ignoring the flag would drop an output the caller asked for
@@ -434,260 +440,355 @@ class Evaluator:
             import torch.distributed as dist
             rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
         model.eval()
-        written: List[str] = []
-        unit = 0                                              # running index of independent units over all clips
-        tm = self.timings = {"load": 0.0, "rasterise": 0.0, "generate": 0.0, "save": 0.0, "frames": 0}
         if self._pool is None:
             self._pool = ThreadPoolExecutor(self.io_threads)          # decode + encode workers
             self._finishers = ThreadPoolExecutor(max(4, self.lanes + 2))  # wait for a unit's copy, then fan out its encodes
-        pool, finishers = self._pool, self._finishers
-        native = hasattr(model, "chain") and hasattr(model, "quantise")
-        gpu_labels = native and self.label_fn is None and hasattr(model, "rasterise")
-        sizes = {}
+        pipe = _FolderPipeline(self, model, rank, world, gt_dir)
+        self.timings = pipe.tm
+        try:
+            with self._plan_policy(model, pipe.native):
+                for sub in [f for f in sorted(os.listdir(pose_dir)) if os.path.isdir(os.path.join(pose_dir, f))]:
+                    print("Evaluating {} .....".format(sub))
+                    clip = pipe.plan_clip(sub, train_dir, dain_dir, pose_dir, save_dir)
+                    if pipe.native:
+                        pipe.run_native(clip)
+                    else:
+                        pipe.run_reference(clip)
+                    clip = None
+                return pipe.drain()
+        finally:
+            del pipe                 # the units' tensor views of the shared blocks die with it ...
+            _shm_trim()              # ... so the surplus blocks can be unmapped
 
-        def image_size(path):                                 # header only; the keypoints scale with THIS image (below)
-            if path not in sizes:
-                with Image.open(path) as im:
-                    sizes[path] = im.size
-            return sizes[path]
 
-        procs = _process_pool(self.io_threads) if (native and self.io_mode == "process" and self._shm_fits()) else None
-        level = self.png_compress_level
+class _Clip:
+    """What this rank renders of one clip, and where every frame's pieces are while the clip is in the pipeline."""
 
-        def save_q(q, name):                                  # uint8 HWC -> file, here or in a worker process
-            if procs is not None:
-                return procs.submit(io_worker.save_png, q, name, level).result(timeout=IO_TIMEOUT_S)
-            return io_worker.save_png(q, name, level)
+    def __init__(self, names, dain_list, image_list, pose_list, gtlist, sample_rate, keys, segs, units):
+        self.names = names                  # output file of every frame index
+        self.dain_list, self.image_list, self.pose_list, self.gtlist = dain_list, image_list, pose_list, gtlist
+        self.sample_rate = sample_rate
+        self.keys = keys                    # this rank's key frames (they pass through, evaluator.py:240-244)
+        self.segs = segs                    # this rank's segments [(key, [frame indices])]
+        self.units = units                  # native path: [(group, [segment indices], c0, c1)] - a unit is a time chunk of a group
+        self.stage = {}                     # unit -> uint8 staging tensor [Tc,B,H,W,3], page-locked; the decoders fill it in place
+        self.stage_blk = {}                 # unit -> the shared block behind it (worker processes)
+        self.slot = {}                      # frame index -> (unit, t, b): where its DAIN frame goes
+        self.loads = {}                     # frame index -> future of (dain | None, key frame | None, pose or rasteriser tables)
+        self.futs = {}                      # frame index -> future of its file name, or (unit future, position in the unit)
+        self.opened = 0                     # units whose staging block and decode tasks exist
+        self.prev_of = {}                   # group -> last fused frames [B,3,H,W] on its lane
 
-        def save_host(x, name):                               # utils/utils.py:129-142 on the host
-            a = np.transpose(x[0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
-            return save_q((np.clip(a, 0, 1) * 255.0).astype(np.uint8), name)
+    def ref_image(self, i):
+        """evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame of its
+        segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale by its size."""
+        return self.gtlist[i] if self.gtlist is not None else self.image_list[i // self.sample_rate]
 
-        t_wall = time.perf_counter()
-        up = None
-        clip_outputs = []                                     # per clip: (names, {frame index: future})
-        # back-pressure is call-wide: at most MAX_UNITS_IN_FLIGHT units (of any clip) are enqueued but not yet written - a unit
-        # holds its label maps and frames on the device and a shared output block on the host until its files exist, and the
-        # GPU renders faster than PNGs get written, so without the window those would pile up over a many-clip folder
-        inflight = collections.deque()
-        tm["peak_units_in_flight"] = 0
-        with self._plan_policy(model, native):
-            for sub in [f for f in sorted(os.listdir(pose_dir)) if os.path.isdir(os.path.join(pose_dir, f))]:
-                print("Evaluating {} .....".format(sub))
-                frames_dir = os.path.join(save_dir, sub)
-                os.makedirs(frames_dir, exist_ok=True)
-                image_list = _list(os.path.join(train_dir, sub), ("jpg", "png"))
-                dain_list = _list(os.path.join(dain_dir, sub), ("jpg", "png"))
-                pose_list = _list(os.path.join(pose_dir, sub), ("json",))
-                sample_rate = sample_rate_of(len(pose_list), len(image_list))
-                seq_len = (len(image_list) - 1) * sample_rate + 1
-                names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
+    def unit_frames(self, ui):
+        _, members, c0, c1 = self.units[ui]
+        return [self.segs[si][1][t] for t in range(c0, c1) for si in members]      # (t, b) order
 
-                gtlist = _list(os.path.join(gt_dir, sub), ("jpg", "png")) if gt_dir is not None else None
-                keys, segs = split_segments(seq_len, sample_rate)
-                # this rank's share: a segment is one unit and brings the key frame it starts from along (that frame is
-                # decoded for the chain anyway); a key frame without a segment (the last one) is a unit of its own
-                first_of = {k: si for si, (k, _) in enumerate(segs)}
-                my_segs, my_keys = [], []
-                for k in keys:
-                    if unit % world == rank:
-                        my_keys.append(k)
-                        if k in first_of:
-                            my_segs.append(first_of[k])
-                    unit += 1
-                segs = [segs[si] for si in my_segs]
-                # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of
-                # the pipeline with one pinned staging buffer that the decode workers fill in place (no stack on the launch
-                # thread, and the upload from pinned memory is asynchronous)
-                units, stage, slot, stage_blk = [], {}, {}, {}
-                if native:
-                    B_ = self.batch or self.default_batch()
-                    for gi, members in enumerate(self.group_segments(segs, B_)):
-                        T = len(segs[members[0]][1])
-                        step = self.chunk if self.chunk > 0 else T
-                        for c0 in range(0, T, step):
-                            units.append((gi, members, c0, min(T, c0 + step)))
 
-                def load(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot):
-                    dain, _ = (self.load_image_u8 if native else self.load_image)(dain_list[i])   # pre-load (evaluator.py:205-235)
-                    if i in slot:
-                        ui, t, b = slot[i]
-                        stage[ui][t, b].copy_(dain)
-                        dain = None
-                    # evaluator.py:209-212: the "gt" image of frame i is gtlist[i] when a gt_dir is given, else the key frame
-                    # of its segment; the keypoints go through A.Resize together with THAT image (:219), i.e. they scale
-                    # by its size, not by the DAIN frame's
-                    ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
-                    gt = self.load_image(ref_img)[0] if i % sample_rate == 0 else None
-                    pose = self.load_pose(pose_list[i], image_size(ref_img))
-                    if gpu_labels:                                 # host tables of the GPU rasteriser, built here in the worker
-                        pose = rasterise.frame_tables(pose[0], pose[1], self.height, self.width, self.skeleton_thres, self.foot_thres)
-                    return dain, gt, pose
+class _FolderPipeline:
+    """One evaluate_from_folder call as explicit stages over units (a unit = `chunk` time steps of a group of up to B segments):
 
-                def load_in_worker(i, dain_list=dain_list, image_list=image_list, pose_list=pose_list, gtlist=gtlist, sample_rate=sample_rate, stage=stage, slot=slot, stage_blk=stage_blk):
-                    """The same pre-load in a worker process; its result is unpacked (the DAIN frame copied into its pinned staging
-                    slot, arrays wrapped as tensors) by the pool's result thread as soon as it arrives."""
-                    from concurrent.futures import Future
-                    ref_img = gtlist[i] if gtlist is not None else image_list[i // sample_rate]
-                    name, off = "", -1
-                    if i in slot:                               # the worker decodes straight into the unit's shared staging block
-                        ui, t, b = slot[i]
-                        name, off = stage_blk[ui].name, (t * stage[ui].shape[1] + b) * self.height * self.width * 3
-                    src = procs.submit(io_worker.load_frame_shm, name, off, dain_list[i], ref_img, pose_list[i], i % sample_rate == 0,
-                                       gpu_labels, self.width, self.height, self.resize, self.skeleton_thres, self.foot_thres)
-                    out = Future()
+        plan_clip   directory listing -> this rank's key frames, segments, groups and units
+        decode      open_units / submit_load: staging block per unit, one decode task per frame (threads or worker processes)
+        upload      DAIN frames + label rasterisation + ToTensor/Normalize on the upload stream
+        render      the unit's batched chain, the quantiser and ONE device-to-host copy on the lane's stream
+        sink        when the copy has landed: PNG encodes, blocks back to the free lists
 
-                    def unpack(f):
-                        try:
-                            _, gt, pose = f.result()
-                            out.set_result((None, torch.from_numpy(io_worker.normalised_chw(gt)) if gt is not None else None, pose))
-                        except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
-                            out.set_exception(e)
-                    src.add_done_callback(unpack)
-                    return out
-                keys = my_keys
-                loads, futs, opened = {}, {}, [0]
+    Windows: decode runs DECODE_AHEAD units ahead of the unit being enqueued; at most MAX_UNITS_IN_FLIGHT units (of any clip)
+    are enqueued but not yet written - a unit holds its label maps and frames on the device and a shared output block on the
+    host until its files exist, and the GPU renders faster than PNGs get written.  Every stage can be driven on its own
+    (tests/test_driver.py)."""
 
-                def submit_load(i):
-                    if i not in loads:
-                        loads[i] = load_in_worker(i) if procs is not None else pool.submit(load, i)
-                        if i in keys and i not in futs:                                # key frames pass through (evaluator.py:240-244)
-                            futs[i] = finishers.submit(lambda k=i, loads=loads, names=names: save_host(loads[k].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), names[k]))
+    def __init__(self, ev, model, rank, world, gt_dir):
+        self.ev, self.model, self.rank, self.world, self.gt_dir = ev, model, rank, world, gt_dir
+        self.native = hasattr(model, "chain") and hasattr(model, "quantise")
+        self.gpu_labels = self.native and ev.label_fn is None and hasattr(model, "rasterise")
+        self.procs = _process_pool(ev.io_threads) if (self.native and ev.io_mode == "process" and ev._shm_fits()) else None
+        self.pool, self.finishers = ev._pool, ev._finishers
+        self.level = ev.png_compress_level
+        self.tm = {"load": 0.0, "rasterise": 0.0, "generate": 0.0, "save": 0.0, "frames": 0, "peak_units_in_flight": 0}
+        self.t_wall = time.perf_counter()
+        self.unit = 0                        # running index of independent units over all clips (the round-robin deal)
+        self.inflight = collections.deque()  # sink futures of the units enqueued but not yet written (call-wide window)
+        self.clips = []
+        self.up = None                       # the upload stream
+        self._sizes = {}
 
-                def open_units(upto):
-                    """Staging block, slots and decode tasks of the units up to index `upto`: the launch thread keeps DECODE_AHEAD units
-                    open beyond the one it is enqueueing, so that host memory (page-locked, shared) does not grow with the clip."""
-                    while opened[0] <= min(upto, len(units) - 1):
-                        ui = opened[0]
-                        gi, members, c0, c1 = units[ui]
-                        if procs is not None:      # shared with the decode workers and page-locked (returned to the free list once uploaded)
-                            nb = (c1 - c0) * len(members) * self.height * self.width * 3
-                            stage_blk[ui] = _shm_get(nb)              # (size classes of 1 MB: the block may be larger than the unit)
-                            stage[ui] = stage_blk[ui].t[:nb].view(c1 - c0, len(members), self.height, self.width, 3)
-                        else:
-                            stage[ui] = torch.empty((c1 - c0, len(members), self.height, self.width, 3), dtype=torch.uint8, pin_memory=True)
-                        for b, si in enumerate(members):
-                            for t in range(c0, c1):
-                                slot[segs[si][1][t]] = (ui, t - c0, b)
-                        # decode in the order the launch thread will ask for the frames: the unit's key frames first
-                        for i in ([segs[si][0] for si in members] if c0 == 0 else []) + [segs[si][1][t] for t in range(c0, c1) for si in members]:
-                            submit_load(i)
-                        opened[0] += 1
+    # ---- helpers --------------------------------------------------------------------------------------------------------
+    def image_size(self, path):              # header only; the keypoints scale with THIS image
+        if path not in self._sizes:
+            from PIL import Image
+            with Image.open(path) as im:
+                self._sizes[path] = im.size
+        return self._sizes[path]
 
-                if not native:
-                    for i in sorted(set(my_keys) | {i for _, frames in segs for i in frames}):
-                        submit_load(i)
-                ngroups = len({u[0] for u in units})
-                lanes = self._lanes(model, ngroups) if native else None
-                prev_of = {}                                                           # group -> last fused frames [B,3,H,W] on its lane
-                for ui, (gi, members, c0, c1) in enumerate(units):
-                    open_units(ui + DECODE_AHEAD)
-                    while len(inflight) >= MAX_UNITS_IN_FLIGHT:      # back-pressure (call-wide window, above): wait for the oldest unit's files
-                        inflight.popleft().result(timeout=IO_TIMEOUT_S)
-                    t0 = time.perf_counter()
-                    Tc, Bc = c1 - c0, len(members)
-                    got = [loads[segs[si][1][t]].result(timeout=IO_TIMEOUT_S) for t in range(c0, c1) for si in members]      # (t, b) order
-                    gt = torch.stack([loads[segs[si][0]].result(timeout=IO_TIMEOUT_S)[1] for si in members]) if c0 == 0 else None
-                    t1 = time.perf_counter()
-                    tm["load"] += t1 - t0
-                    poses = [g_[2] for g_ in got]
-                    g, st = lanes[gi % len(lanes)] if lanes else (model, torch.cuda.current_stream(model.device))
-                    # uploads (pageable host memory: synchronous with respect to their stream) and the label
-                    # rasterisation go to a stream of their own, which is idle, so that they do not wait behind
-                    # the previous unit of this lane; the lane joins through an event
-                    if up is None:
-                        up = torch.cuda.Stream(device=model.device)
-                    with torch.cuda.stream(up):
-                        if gpu_labels:
-                            lab = rasterise.rasterise_tables(g, poses, self.height, self.width, self.gauss_sigma)
-                        else:
-                            lab = self.make_labels(g if hasattr(g, "rasterise") else model, poses)
-                        lab = lab.to(g.device).reshape(Tc, Bc, *lab.shape[1:])            # [Tc,B,22,H,W]
-                        # ToTensor + Normalize(0.5, 0.5) of the uint8 frames on the GPU (HSM_auto_dataset.py:73-75)
-                        dn = stage[ui].to(g.device, non_blocking=True).permute(0, 1, 4, 2, 3).to(torch.float32)
-                        dn = ((dn / 255.0 - 0.5) / 0.5).contiguous()                      # [Tc,B,3,H,W]
-                        gtd = gt.to(g.device) if gt is not None else None
-                        ready = torch.cuda.Event()
-                        ready.record(up)
-                    for t_ in (lab, dn, gtd):
-                        if t_ is not None:
-                            t_.record_stream(st)
-                    with torch.cuda.stream(st):
-                        st.wait_event(ready)
-                        t2 = time.perf_counter()
-                        # evaluator.py:240-244,252: a segment starts from its key frame; inside it prev <- fused frame
-                        fz = g.chain(gtd if c0 == 0 else prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
-                        prev_of[gi] = fz[-1]
-                        q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
-                        out_blk = _shm_get(q.numel()) if procs is not None else None       # shared with the encode workers, page-locked
-                        pinned = out_blk.t[:q.numel()].view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
-                        pinned.copy_(q, non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(st)
-                    tm["rasterise"] += t2 - t1
-                    tm["generate"] += time.perf_counter() - t2
-                    out_frames = [segs[si][1][t] for t in range(c0, c1) for si in members]
+    def save_q(self, q, name):               # uint8 HWC -> file, here or in a worker process
+        if self.procs is not None:
+            return self.procs.submit(io_worker.save_png, q, name, self.level).result(timeout=IO_TIMEOUT_S)
+        return io_worker.save_png(q, name, self.level)
 
-                    t_enq = time.perf_counter() - t_wall
+    def save_host(self, x, name):            # utils/utils.py:129-142 on the host
+        a = np.transpose(x[0].cpu().float().numpy(), (1, 2, 0)) * np.array([0.5] * 3) + np.array([0.5] * 3)
+        return self.save_q((np.clip(a, 0, 1) * 255.0).astype(np.uint8), name)
 
-                    def finish(done=done, pinned=pinned, out_frames=out_frames, names=names, keep=(fz, q, lab, dn, gtd), in_blk=stage_blk.get(ui),
-                               out_blk=out_blk, t_enq=t_enq, t_loaded=t1 - t_wall):
-                        done.synchronize()                      # the chain, the quantiser and the download are done: so is the upload
-                        # per unit: inputs decoded, launches enqueued, results on the host, files written (seconds since the call began)
-                        mark = [round(t_loaded, 4), round(t_enq, 4), round(time.perf_counter() - t_wall, 4)]
-                        tm.setdefault("timeline", []).append(mark)
-                        if in_blk is not None:
-                            _shm_put(in_blk)
-                        if out_blk is not None:
-                            fsz = self.height * self.width * 3
-                            fs = [procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, self.height, self.width, names[out_frames[j]], level)
-                                  for j in range(len(out_frames))]
-                            res = [f.result(timeout=IO_TIMEOUT_S) for f in fs]
-                            _shm_put(out_blk)
-                            mark.append(round(time.perf_counter() - t_wall, 4))
-                            return res
-                        qn = pinned.numpy()
-                        res = list(pool.map(lambda j: save_q(qn[j], names[out_frames[j]]), range(len(out_frames))))
-                        mark.append(round(time.perf_counter() - t_wall, 4))
-                        return res
-                    seg_fut = finishers.submit(finish)
-                    inflight.append(seg_fut)
-                    tm["peak_units_in_flight"] = max(tm["peak_units_in_flight"], len(inflight))
-                    for j, i in enumerate(out_frames):
-                        futs[i] = (seg_fut, j)
-                for k in keys:
-                    submit_load(k)
-                tm["units"] = tm.get("units", 0) + len(units)
-                for si, (k, frames) in enumerate([] if native else segs):             # any reference-protocol callable
-                    t0 = time.perf_counter()
-                    got = [loads[i].result() for i in frames]
-                    gt = loads[k].result()[1].unsqueeze(0)
-                    t1 = time.perf_counter()
-                    tm["load"] += t1 - t0
-                    poses = [g[2] for g in got]
-                    dn = torch.stack([g[0] for g in got]).unsqueeze(1)
-                    lab = self.make_labels(model, poses).unsqueeze(1)
-                    t2 = time.perf_counter()
-                    prev, outs = gt, []
-                    for t in range(len(frames)):
-                        img, mask = model(lab[t], None, dn[t], prev)
-                        prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
-                        outs.append(prev)
-                    tm["rasterise"] += t2 - t1
-                    tm["generate"] += time.perf_counter() - t2
-                    for t, i in enumerate(frames):
-                        futs[i] = pool.submit(save_host, outs[t], names[i])
-                clip_outputs.append((names, futs))
-                tm["frames"] += len(futs)
-            t5 = time.perf_counter()
-            for names, futs in clip_outputs:                                           # frame order, as the reference writes them
-                for i, name in enumerate(names):
-                    if i not in futs:
-                        continue                                                       # another rank's frame
-                    f = futs[i]
-                    res = f[0].result()[f[1]] if isinstance(f, tuple) else f.result()
-                    assert res == name
-                    written.append(name)
-            tm["save"] = time.perf_counter() - t5                                      # tail: encodes still running after the last enqueue
-            tm["wall"] = time.perf_counter() - t_wall
+    # ---- stage 0: plan ---------------------------------------------------------------------------------------------------
+    def plan_clip(self, sub, train_dir, dain_dir, pose_dir, save_dir):
+        ev = self.ev
+        frames_dir = os.path.join(save_dir, sub)
+        os.makedirs(frames_dir, exist_ok=True)
+        image_list = _list(os.path.join(train_dir, sub), ("jpg", "png"))
+        dain_list = _list(os.path.join(dain_dir, sub), ("jpg", "png"))
+        pose_list = _list(os.path.join(pose_dir, sub), ("json",))
+        sample_rate = sample_rate_of(len(pose_list), len(image_list))
+        seq_len = (len(image_list) - 1) * sample_rate + 1
+        names = [os.path.join(frames_dir, os.path.basename(dain_list[i]))[:-4] + ".png" for i in range(seq_len)]
+        gtlist = _list(os.path.join(self.gt_dir, sub), ("jpg", "png")) if self.gt_dir is not None else None
+        keys, segs = split_segments(seq_len, sample_rate)
+        # this rank's share: a segment is one unit of the deal and brings the key frame it starts from along (that frame is
+        # decoded for the chain anyway); a key frame without a segment (the last one) is a unit of its own
+        first_of = {k: si for si, (k, _) in enumerate(segs)}
+        my_segs, my_keys = [], []
+        for k in keys:
+            if self.unit % self.world == self.rank:
+                my_keys.append(k)
+                if k in first_of:
+                    my_segs.append(first_of[k])
+            self.unit += 1
+        segs = [segs[si] for si in my_segs]
+        # native path: segments of equal length are grouped into batches, every (group, time chunk) is one unit of the pipeline
+        # with one pinned staging buffer that the decode workers fill in place
+        units = []
+        if self.native:
+            B_ = ev.batch or ev.default_batch()
+            for gi, members in enumerate(ev.group_segments(segs, B_)):
+                T = len(segs[members[0]][1])
+                step = ev.chunk if ev.chunk > 0 else T
+                for c0 in range(0, T, step):
+                    units.append((gi, members, c0, min(T, c0 + step)))
+        clip = _Clip(names, dain_list, image_list, pose_list, gtlist, sample_rate, my_keys, segs, units)
+        self.clips.append(clip)
+        return clip
+
+    # ---- stage 1: decode -------------------------------------------------------------------------------------------------
+    def decode_here(self, clip, i):
+        """Pre-load of frame i on a pool thread (evaluator.py:205-235)."""
+        ev = self.ev
+        dain, _ = (ev.load_image_u8 if self.native else ev.load_image)(clip.dain_list[i])
+        if i in clip.slot:
+            ui, t, b = clip.slot[i]
+            clip.stage[ui][t, b].copy_(dain)
+            dain = None
+        ref_img = clip.ref_image(i)
+        gt = ev.load_image(ref_img)[0] if i % clip.sample_rate == 0 else None
+        pose = ev.load_pose(clip.pose_list[i], self.image_size(ref_img))
+        if self.gpu_labels:                      # host tables of the GPU rasteriser, built here in the worker
+            pose = rasterise.frame_tables(pose[0], pose[1], ev.height, ev.width, ev.skeleton_thres, ev.foot_thres)
+        return dain, gt, pose
+
+    def decode_in_worker(self, clip, i):
+        """The same pre-load in a worker process; its result is unpacked (arrays wrapped as tensors) by the pool's result thread
+        as soon as it arrives.  The worker decodes the DAIN frame straight into the unit's shared staging block."""
+        from concurrent.futures import Future
+        ev = self.ev
+        name, off = "", -1
+        if i in clip.slot:
+            ui, t, b = clip.slot[i]
+            name, off = clip.stage_blk[ui].name, (t * clip.stage[ui].shape[1] + b) * ev.height * ev.width * 3
+        src = self.procs.submit(io_worker.load_frame_shm, name, off, clip.dain_list[i], clip.ref_image(i), clip.pose_list[i],
+                                i % clip.sample_rate == 0, self.gpu_labels, ev.width, ev.height, ev.resize, ev.skeleton_thres, ev.foot_thres)
+        out = Future()
+
+        def unpack(f):
+            try:
+                _, gt, pose = f.result()
+                out.set_result((None, torch.from_numpy(io_worker.normalised_chw(gt)) if gt is not None else None, pose))
+            except BaseException as e:              # noqa: BLE001 (handed to whoever waits for the frame)
+                out.set_exception(e)
+        src.add_done_callback(unpack)
+        return out
+
+    def submit_load(self, clip, i):
+        if i in clip.loads:
+            return
+        clip.loads[i] = self.decode_in_worker(clip, i) if self.procs is not None else self.pool.submit(self.decode_here, clip, i)
+        if i in clip.keys and i not in clip.futs:          # key frames pass through (evaluator.py:240-244)
+            clip.futs[i] = self.finishers.submit(
+                lambda: self.save_host(clip.loads[i].result(timeout=IO_TIMEOUT_S)[1].unsqueeze(0), clip.names[i]))
+
+    def open_units(self, clip, upto):
+        """Staging block, slots and decode tasks of the units up to index `upto`: the launch thread keeps DECODE_AHEAD units open
+        beyond the one it is enqueueing, so that host memory (page-locked, shared) does not grow with the clip."""
+        ev = self.ev
+        while clip.opened <= min(upto, len(clip.units) - 1):
+            ui = clip.opened
+            _, members, c0, c1 = clip.units[ui]
+            shape = (c1 - c0, len(members), ev.height, ev.width, 3)
+            if self.procs is not None:      # shared with the decode workers and page-locked (back on the free list once uploaded)
+                nb = shape[0] * shape[1] * ev.height * ev.width * 3
+                clip.stage_blk[ui] = _shm_get(nb)               # (size classes of 1 MB: the block may be larger than the unit)
+                clip.stage[ui] = clip.stage_blk[ui].t[:nb].view(*shape)
+            else:
+                clip.stage[ui] = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+            for b, si in enumerate(members):
+                for t in range(c0, c1):
+                    clip.slot[clip.segs[si][1][t]] = (ui, t - c0, b)
+            # decode in the order the launch thread will ask for the frames: the unit's key frames first
+            for i in ([clip.segs[si][0] for si in members] if c0 == 0 else []) + clip.unit_frames(ui):
+                self.submit_load(clip, i)
+            clip.opened += 1
+
+    # ---- stage 2: upload -------------------------------------------------------------------------------------------------
+    def wait_decoded(self, clip, ui):
+        """Blocks until the unit's frames (and, for a first chunk, its key frames) are decoded: (poses or tables, key frames)."""
+        _, members, c0, _ = clip.units[ui]
+        got = [clip.loads[i].result(timeout=IO_TIMEOUT_S) for i in clip.unit_frames(ui)]
+        gt = torch.stack([clip.loads[clip.segs[si][0]].result(timeout=IO_TIMEOUT_S)[1] for si in members]) if c0 == 0 else None
+        return [g_[2] for g_ in got], gt
+
+    def upload(self, clip, ui, g, st, poses, gt):
+        """Enqueues - on the upload stream, which is idle, so that nothing waits behind the previous unit of the lane - the label
+        rasterisation, the upload of the staged DAIN frames with ToTensor + Normalize(0.5, 0.5) on the GPU
+        (HSM_auto_dataset.py:73-75) and the key frames; the lane joins through the returned event.  -> (lab, dn, gtd, ready)."""
+        ev = self.ev
+        _, members, c0, c1 = clip.units[ui]
+        Tc, Bc = c1 - c0, len(members)
+        if self.up is None:
+            self.up = torch.cuda.Stream(device=self.model.device)
+        with torch.cuda.stream(self.up):
+            if self.gpu_labels:
+                lab = rasterise.rasterise_tables(g, poses, ev.height, ev.width, ev.gauss_sigma)
+            else:
+                lab = ev.make_labels(g if hasattr(g, "rasterise") else self.model, poses)
+            lab = lab.to(g.device).reshape(Tc, Bc, *lab.shape[1:])            # [Tc,B,22,H,W]
+            dn = clip.stage[ui].to(g.device, non_blocking=True).permute(0, 1, 4, 2, 3).to(torch.float32)
+            dn = ((dn / 255.0 - 0.5) / 0.5).contiguous()                      # [Tc,B,3,H,W]
+            gtd = gt.to(g.device) if gt is not None else None
+            ready = torch.cuda.Event()
+            ready.record(self.up)
+        for t_ in (lab, dn, gtd):
+            if t_ is not None:
+                t_.record_stream(st)
+        return lab, dn, gtd, ready
+
+    # ---- stage 3: render -------------------------------------------------------------------------------------------------
+    def render(self, clip, ui, g, st, lab, dn, gtd, ready):
+        """The unit's chain (evaluator.py:240-244,252: a segment starts from its key frame; inside it prev <- fused frame), the
+        quantiser and ONE asynchronous copy into page-locked host memory, all on the lane's stream.  Returns what the sink needs."""
+        gi, _, c0, _ = clip.units[ui]
+        with torch.cuda.stream(st):
+            st.wait_event(ready)
+            fz = g.chain(gtd if c0 == 0 else clip.prev_of[gi], lab, dn, want_all=False)[2]      # [Tc,B,3,H,W]
+            clip.prev_of[gi] = fz[-1]
+            q = g.quantise(fz.reshape(-1, *fz.shape[2:]))                  # [Tc*B,H,W,3] uint8
+            out_blk = _shm_get(q.numel()) if self.procs is not None else None       # shared with the encode workers, page-locked
+            pinned = out_blk.t[:q.numel()].view(q.shape) if out_blk is not None else torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+            pinned.copy_(q, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(st)
+        return {"done": done, "pinned": pinned, "out_blk": out_blk, "keep": (fz, q, lab, dn, gtd)}
+
+    # ---- stage 4: sink ---------------------------------------------------------------------------------------------------
+    def sink(self, clip, ui, r, t_loaded, t_enq):
+        """Runs on a finisher thread: waits for the unit's copy, hands the staging block back, fans the PNG encodes out and
+        returns the written names in unit order.  `r["keep"]` keeps the unit's device tensors alive until then."""
+        ev = self.ev
+        out_frames = clip.unit_frames(ui)
+        r["done"].synchronize()                 # the chain, the quantiser and the download are done: so is the upload
+        # per unit: inputs decoded, launches enqueued, results on the host, files written (seconds since the call began)
+        mark = [round(t_loaded, 4), round(t_enq, 4), round(time.perf_counter() - self.t_wall, 4)]
+        self.tm.setdefault("timeline", []).append(mark)
+        in_blk = clip.stage_blk.pop(ui, None)
+        clip.stage.pop(ui, None)                # (the view of the block goes before the block does)
+        if in_blk is not None:
+            _shm_put(in_blk)
+        out_blk = r["out_blk"]
+        if out_blk is not None:
+            fsz = ev.height * ev.width * 3
+            fs = [self.procs.submit(io_worker.save_png_shm, out_blk.name, j * fsz, ev.height, ev.width, clip.names[out_frames[j]], self.level)
+                  for j in range(len(out_frames))]
+            res = [f.result(timeout=IO_TIMEOUT_S) for f in fs]
+            r["pinned"] = None
+            _shm_put(out_blk)
+        else:
+            qn = r["pinned"].numpy()
+            res = list(self.pool.map(lambda j: self.save_q(qn[j], clip.names[out_frames[j]]), range(len(out_frames))))
+        r["keep"] = None
+        mark.append(round(time.perf_counter() - self.t_wall, 4))
+        return res
+
+    # ---- drivers ---------------------------------------------------------------------------------------------------------
+    def run_native(self, clip):
+        tm = self.tm
+        ngroups = len({u[0] for u in clip.units})
+        lanes = self.ev._lanes(self.model, ngroups)
+        for ui, (gi, members, c0, c1) in enumerate(clip.units):
+            self.open_units(clip, ui + DECODE_AHEAD)
+            while len(self.inflight) >= MAX_UNITS_IN_FLIGHT:      # back-pressure (call-wide window): wait for the oldest unit's files
+                self.inflight.popleft().result(timeout=IO_TIMEOUT_S)
+            g, st = lanes[gi % len(lanes)] if lanes else (self.model, torch.cuda.current_stream(self.model.device))
+            t0 = time.perf_counter()
+            poses, gt = self.wait_decoded(clip, ui)
+            t1 = time.perf_counter()
+            lab, dn, gtd, ready = self.upload(clip, ui, g, st, poses, gt)
+            t2 = time.perf_counter()
+            r = self.render(clip, ui, g, st, lab, dn, gtd, ready)
+            t3 = time.perf_counter()
+            tm["load"] += t1 - t0
+            tm["rasterise"] += t2 - t1
+            tm["generate"] += t3 - t2
+            seg_fut = self.finishers.submit(self.sink, clip, ui, r, t1 - self.t_wall, t3 - self.t_wall)
+            self.inflight.append(seg_fut)
+            tm["peak_units_in_flight"] = max(tm["peak_units_in_flight"], len(self.inflight))
+            for j, i in enumerate(clip.unit_frames(ui)):
+                clip.futs[i] = (seg_fut, j)
+        for k in clip.keys:
+            self.submit_load(clip, k)
+        tm["units"] = tm.get("units", 0) + len(clip.units)
+        tm["frames"] += len(clip.futs)
+
+    def run_reference(self, clip):
+        """Any callable that only speaks the reference's protocol (img, mask = model(label, None, dain, prev)): frame by frame."""
+        ev, tm, model = self.ev, self.tm, self.model
+        for i in sorted(set(clip.keys) | {i for _, frames in clip.segs for i in frames}):
+            self.submit_load(clip, i)
+        for k, frames in clip.segs:
+            t0 = time.perf_counter()
+            got = [clip.loads[i].result() for i in frames]
+            gt = clip.loads[k].result()[1].unsqueeze(0)
+            t1 = time.perf_counter()
+            tm["load"] += t1 - t0
+            poses = [g[2] for g in got]
+            dn = torch.stack([g[0] for g in got]).unsqueeze(1)
+            lab = ev.make_labels(model, poses).unsqueeze(1)
+            t2 = time.perf_counter()
+            prev, outs = gt, []
+            for t in range(len(frames)):
+                img, mask = model(lab[t], None, dn[t], prev)
+                prev = img * mask.repeat(1, 3, 1, 1) + dn[t].to(img.device) * (1 - mask.repeat(1, 3, 1, 1))
+                outs.append(prev)
+            tm["rasterise"] += t2 - t1
+            tm["generate"] += time.perf_counter() - t2
+            for t, i in enumerate(frames):
+                clip.futs[i] = self.pool.submit(self.save_host, outs[t], clip.names[i])
+        tm["units"] = tm.get("units", 0)
+        tm["frames"] += len(clip.futs)
+
+    def drain(self):
+        """Waits for every file of the call, in frame order as the reference writes them; returns the names this rank wrote."""
+        written: List[str] = []
+        t5 = time.perf_counter()
+        for clip in self.clips:
+            for i, name in enumerate(clip.names):
+                if i not in clip.futs:
+                    continue                                                       # another rank's frame
+                f = clip.futs[i]
+                res = f[0].result()[f[1]] if isinstance(f, tuple) else f.result()
+                assert res == name
+                written.append(name)
+        self.tm["save"] = time.perf_counter() - t5                                 # tail: encodes still running after the last enqueue
+        self.tm["wall"] = time.perf_counter() - self.t_wall
         return written

@@ -212,6 +212,12 @@ class Generator:
                 for op in self._tuning["%d,%d,%d" % (TB, H, W)]:
                     self._lib.rib_set_choice(self._h, TB, H, W, op.encode(), -1, 1)
                 self._applied[(TB, H, W)] = self._tuned[key] = 0
+                # erasing the choices of (TB, H, W) rebuilds EVERY plan that follows TB, other batch sizes included: the
+                # workspaces cached for them were sized under the old choices (rib_forward / rib_chain reject a workspace
+                # smaller than the current plan needs, so a stale one could only fail loudly - but it need not fail at all)
+                self._ws.clear()
+                self.__dict__.pop("_chain_ws", None)
+                self.__dict__.pop("_chain_out", None)
                 n = self._lib.rib_workspace_bytes(self._h, B, H, W)
             if n == 0:
                 _native.check(self._h, -1)

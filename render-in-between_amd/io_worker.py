@@ -7,6 +7,8 @@ enqueues the GPU work (profiles/r04_driver.jsonl: the launch thread spent 0.1-0.
 Reference semantics: PGNR/models/evaluator.py:205-235 (per-frame pre-load), PGNR/utils/utils.py:129-142 (save)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import rasterise
@@ -82,6 +84,10 @@ def _attach(name):
     shm = _SHM.get(name)
     if shm is None:
         from multiprocessing import shared_memory
+        # a miss is the moment to forget blocks the parent has retired since (Evaluator._shm_trim unlinks them: the name is gone
+        # from /dev/shm, but the pages stay allocated for as long as a process maps them)
+        for gone in [n for n in _SHM if not os.path.exists("/dev/shm/" + n.lstrip("/"))]:
+            _SHM.pop(gone).close()
         if len(_SHM) > 64:
             for old in _SHM.values():
                 old.close()
