@@ -952,10 +952,51 @@ static int xcd_chunk_of(int tiles) {
   return (!off && tiles >= 64 && tiles % 8 == 0) ? tiles / 8 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// FusionPolicy: every decision of the launch plan that is a POLICY rather than arithmetic - which launches are fused, which
+// kernel family serves a layer, where a tensor is never materialised - by name, with the switch that turns it off for an
+// A/B or a test.  One instance per plan build, read from the environment at that moment (tests flip the switches between
+// two Generator constructions).  Three more switches act where the weight LAYOUT is assigned, because they decide which
+// filter copies exist at all (assign_weight_layout: RIB_NO_WINO, RIB_NO_LOWC, RIB_NO_SPADE16), one where the k_gemm_dma tile
+// of a GEMM is picked (pick_gemm_dma: RIB_NO_DMA), one in the tile order of a grid (xcd_chunk_of: RIB_NO_XCD).
+// The tuned tables (rib_set_choice) choose WITHIN what the policy allows: tile variant, split-K factor, Winograd tile.
+// ------------------------------------------------------------------------------------------
+struct FusionPolicy {
+  // InstanceNorm statistics: a consumer that can reduce <= STATS_MAX_PARTIALS producer partials itself does so and the
+  // k_stats_finalize launch never exists (RIB_NO_CONSUMER_STATS=1: one finalize launch per normalised tensor)
+  bool consumer_stats = !getenv("RIB_NO_CONSUMER_STATS");
+  // heads with <= 3 output channels: k_conv_head (taps as MFMA columns; RIB_NO_HEADCONV=1 -> k_conv_small, direct on the
+  // vector ALUs; RIB_NO_SMALLCONV=1 -> k_igemm with the columns padded to 16)
+  bool head_conv = !getenv("RIB_NO_HEADCONV");
+  bool small_conv = !getenv("RIB_NO_SMALLCONV");
+  // 3x3 stride-1 layers on maps of at most this many pixels run in the Winograd domain (k_wino_in / batched GEMM / k_wino_out)
+  long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
+  int wino_force = getenv("RIB_WINO_M") ? atoi(getenv("RIB_WINO_M")) : 0;      // 2 / 4: that Winograd tile wherever one is eligible
+  // grid-level split-K (+ a k_splitk_epilogue launch) for layers whose tile grid cannot fill the chip
+  bool split_k = !getenv("RIB_NO_SPLITK");
+  // layers with <= 16 output channels on the 16-column MFMA path (v_mfma_f32_16x16x4_f32; fp32 storage only)
+  bool n16 = !getenv("RIB_NO_N16");
+  // k_conv_lowc tile width: 0 = per layer (16 for the store-bound 64-column layer without statistics, else 32)
+  int lowc_tw = getenv("RIB_LOWC_TW") ? (atoi(getenv("RIB_LOWC_TW")) == 16 ? 16 : 32) : 0;
+  // condition levels of at most this many pixels compute gamma/beta of ALL their SPADEs in one GEMM into a slab (0: off)
+  long cond_gemm_max_px = getenv("RIB_COND_GEMM_MAX_PX") ? atol(getenv("RIB_COND_GEMM_MAX_PX")) : 4096;
+  // SPADE on maps of <= 4096 pixels (x batch): unfused (slab GEMM + k_spade_modulate) instead of k_igemm<SPADE>
+  bool unfused_spade = !getenv("RIB_NO_UNFUSED_SPADE");
+  // an unfused SPADE's output / a mask-network join whose only consumer is a Winograd input transform is never stored
+  bool lazy_sources = !getenv("RIB_NO_LAZY");
+  // the learned 1x1 shortcut of a res block as extra K chunks of conv_block_1 (one launch less, no shortcut tensor)
+  bool fuse_shortcut = !getenv("RIB_NO_FUSE_SHORTCUT");
+  // buffers with disjoint lifetimes share workspace bytes (assign_physical)
+  bool ws_reuse = !getenv("RIB_NO_WS_REUSE");
+  // level i of the mask network's label encoder and of its image encoder in ONE paired launch (batch-1 frame plans)
+  bool pair_mask_encoders = !getenv("RIB_NO_PAIR");
+};
+
 struct Builder {
   rib_handle* h;
   Plan* P;
   int B;
+  const FusionPolicy pol;
   size_t ws = 0;
   std::string error;
   bool mark_label = false;
@@ -969,8 +1010,7 @@ struct Builder {
   static bool has_partials(const Norm& n) { return n.pend && !n.pend->pushed; }
   // emit or defer the finalize launch f of a producer with `tiles` partials per sample
   void finalize_or_defer(Op& f, Norm* out, bool now, size_t part_off, int tiles, int Cs, float inv_count, bool affine, size_t g_off, size_t be_off) {
-    static const bool off = getenv("RIB_NO_CONSUMER_STATS") != nullptr;
-    if (now || off || !defer_stats || mark_label || tiles > STATS_MAX_PARTIALS) { push(f); return; }
+    if (now || !pol.consumer_stats || !defer_stats || mark_label || tiles > STATS_MAX_PARTIALS) { push(f); return; }
     auto ps = std::make_shared<PendingStats>();
     ps->fin = f; ps->part_off = part_off; ps->tiles = tiles; ps->Cs = Cs; ps->inv_count = inv_count;
     ps->affine = affine; ps->g_off = g_off; ps->be_off = be_off;
@@ -1042,7 +1082,7 @@ struct Builder {
   }
   // conv_img can skip its NHWC copy only on the head kernel (conv(): `small` + `head`)
   bool head_without_nhwc(const ConvDef& c) {
-    return c.cout <= 3 && c.ks == 3 && c.stride == 1 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_SMALLCONV") && !getenv("RIB_NO_HEADCONV");
+    return c.cout <= 3 && c.ks == 3 && c.stride == 1 && (c.cinp == 16 || c.cinp == 32) && pol.small_conv && pol.head_conv;
   }
   static PRef WS(size_t off) { PRef r; r.sp = PS_WS; r.off = off; return r; }
   static PRef WT(size_t off) { PRef r; r.sp = PS_WEIGHT; r.off = off; return r; }
@@ -1080,10 +1120,9 @@ struct Builder {
   // maps up to 128x128 (1024x1024 frames: +3.5 % at batch 1 and 4); beyond that V and M (4x the activation each)
   // leave the caches and the direct kernel, which fills the chip there, was not beaten
   bool runs_wino(const ConvArgs& a, int Hout, int Wout) const {
-    static const long wino_max_px = getenv("RIB_WINO_MAX_PX") ? atol(getenv("RIB_WINO_MAX_PX")) : 16384;
     const ConvDef& c = *a.cd;
     return h->prec() == PREC_F32 && c.wino_ok && !a.ups && !a.aux && !a.res_ups && !a.pair && !a.in.virt && a.y_nchw.sp == PS_NULL &&
-           a.y_user.sp == PS_NULL && (long)Hout * Wout <= wino_max_px && Hout >= 2 && Wout >= 2;
+           a.y_user.sp == PS_NULL && (long)Hout * Wout <= pol.wino_max_px && Hout >= 2 && Wout >= 2;
   }
   // would conv `cd` on an HxW map (stride 1, plain arguments) run in the Winograd domain?  (callers that want to hand it a lazy input)
   bool would_wino(const ConvDef& cd, int H, int W) const { ConvArgs t; t.cd = &cd; return runs_wino(t, H, W); }
@@ -1107,9 +1146,9 @@ struct Builder {
     if (a.in.lazy) { error = opname + ": a lazy input (" + a.in.lazy->name + ") needs the Winograd path"; return false; }
     // split-K needs the slab-summing epilogue: float4 channel groups that tile a 256-thread block,
     // and no NCHW side copy
-    const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !a.pair && !a.no_split && !getenv("RIB_NO_SPLITK");
+    const bool can_split = (256 % (c.coutp / 4) == 0) && a.y_nchw.sp == PS_NULL && !a.pair && !a.no_split && pol.split_k;
     // the 16-column path serves layers with <= 16 output channels and no residual read
-    const bool can_n16 = c.cout <= 16 && !a.res && !h->mc16() && !getenv("RIB_NO_N16");
+    const bool can_n16 = c.cout <= 16 && !a.res && !h->mc16() && pol.n16;
     Choice ch = choose_variant(h->prec(), c.stride, c.ks, a.ups, false, c.coutp, TB_(), Hout, Wout, c.cinp, can_split, a.aux ? a.aux->cinp : 0, can_n16);
     {
       auto it = h->choices.end();
@@ -1148,7 +1187,7 @@ struct Builder {
     // matrix-core kernels would pad N to 16 columns.  y_nchw's channel count is Cout of the conv itself.
     const bool small = c.cout <= 4 && c.ks == 3 && c.stride == 1 && !a.ups && !a.res && !a.aux && !a.want_stats &&
                        c.cinp <= 32 && 256 % (c.cinp / 4) == 0 &&   // halo tile + filter within the default 64 KB of dynamic LDS
-                       !getenv("RIB_NO_SMALLCONV");
+                       pol.small_conv;
     if (a.pro) {
       // (a consumer-side finalize in the PROLOGUE was tried and removed: its (scale, shift) table cost every prologue
       // variant 4 KB of LDS - an occupancy step for several of them - to save four launches; the SPADE epilogue keeps its own)
@@ -1184,12 +1223,12 @@ struct Builder {
     }
     if (a.res) { op.res = WS(a.res->off); p.resC = a.res->Cp; p.res_ups = a.res_ups ? 1 : 0; }
     op.y_nchw = a.y_nchw;
-    if (a.y_none && !(small && c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV") && a.y_nchw.sp != PS_NULL)) {
+    if (a.y_none && !(small && c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && pol.head_conv && a.y_nchw.sp != PS_NULL)) {
       error = opname + ": only the head kernel can run without an NHWC destination"; return false;
     }
     if (small) {
       op.small_co = c.cout;
-      op.head = c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && !getenv("RIB_NO_HEADCONV");
+      op.head = c.cout <= 3 && (c.cinp == 16 || c.cinp == 32) && pol.head_conv;
       // the mask head has every pixel's mask in a register: the driver's blend (evaluator.py:256-258) rides along
       op.fuse_blend = op.head && c.cout == 1 && a.y_user.sp == PS_USER && a.y_user.off == (size_t)U_MASK;
       p.bl_C = h->g.c.image_nc;
@@ -1263,7 +1302,7 @@ struct Builder {
     // 8x16 tiles (2048 workgroups at 512x512: two rounds, whose gather / MFMA / store phases overlap) win where the layer is
     // store-bound and has no statistics (conv_first 44.6 -> 38.4 us); with statistics the finalize of twice the partials
     // eats the gain (down_lbl.0 -3 +3 us) and the 16-column layer loses (29.5 -> 32.7)
-    const int tw = getenv("RIB_LOWC_TW") ? (atoi(getenv("RIB_LOWC_TW")) == 16 ? 16 : 32) : ((c.lowc_ncol == 64 && !a.want_stats) ? 16 : 32);
+    const int tw = pol.lowc_tw ? pol.lowc_tw : ((c.lowc_ncol == 64 && !a.want_stats) ? 16 : 32);
     op.lowc_tw = tw;
     p.tilesX = (W + tw - 1) / tw; p.tilesY = (H + 7) / 8;
     if (p.Cout > c.lowc_ncol || c.cout > c.lowc_ncol) { error = opname + ": more output columns than the k_conv_lowc instantiation has"; return false; }
@@ -1298,7 +1337,7 @@ struct Builder {
     // rows) and F(2x2, 3x3) (16 positions, 4/9) is faster.  Measured per layer at 512x512, transforms included:
     // 256->256 at 64x64 42.4 -> 37.3 us, 512->256 at 64x64 67.4 -> 56.2; 512->512 at 32x32 38.3 -> 41.0 (kept on F(2x2)).
     // RIB_WINO_M = 2 / 4 forces one of them.
-    const int wino_force = getenv("RIB_WINO_M") ? atoi(getenv("RIB_WINO_M")) : 0;
+    const int wino_force = pol.wino_force;
     const int wm = wino_force == 2 || wino_force == 4 ? wino_force : ((long)TB_() * ((Hout + 3) / 4) * ((Wout + 3) / 4) >= 256 ? 4 : 2);
     const int NP = (wm + 2) * (wm + 2);      // output tile edge, Winograd positions
     const int tilesY = (Hout + wm - 1) / wm, tilesX = (Wout + wm - 1) / wm, ntiles = tilesY * tilesX;
@@ -1425,7 +1464,7 @@ struct Builder {
   // 8.6 GFLOP each) writes a slab [B][H*W][N] and every SPADE of the level is then only its k_spade_modulate on its own
   // column range.  Levels whose map is larger stay fused (gamma/beta never touch memory there).
   bool cond_level_gemm(int level, const Act& cond) {
-    static const long max_px = getenv("RIB_COND_GEMM_MAX_PX") ? atol(getenv("RIB_COND_GEMM_MAX_PX")) : 4096;   // 0: off
+    const long max_px = pol.cond_gemm_max_px;   // 0: off
     const auto it = h->level_groups.find(level);
     if (it == h->level_groups.end() || it->second.size() < 2 || (long)TB_() * cond.H * cond.W > max_px) return true;
     int N = 0; double fl = 0.0;
@@ -1505,7 +1544,7 @@ struct Builder {
         if (t.SPADE && t.NF == 1 && t.BF16 == h->prec() && t.KW == 1 && t.TB == 1 && cond.Cp % t.BK == 0) { v = &t; break; }
       }
     Choice uf;   // unfused candidate
-    const bool small_map = (long)Hout * Wout * TB_() <= 4096 && !getenv("RIB_NO_UNFUSED_SPADE");
+    const bool small_map = (long)Hout * Wout * TB_() <= 4096 && pol.unfused_spade;
     if (small_map) uf = choose_variant(h->prec(), 1, 1, false, false, sg.npad, TB_(), Hout, Wout, cond.Cp, true);
     bool unfused = small_map && uf.v != nullptr;
     {
@@ -1526,7 +1565,7 @@ struct Builder {
     const bool from_level = lvl != level_slab.end();
     if (from_level) unfused = true;
     if (!unfused && !v) { error = "no SPADE variant"; return false; }
-    static const bool no_lazy = getenv("RIB_NO_LAZY") != nullptr;
+    const bool no_lazy = !pol.lazy_sources;
     if (from_level && lazy_ok && sg.nsets == 1 && !h->keep_taps && !no_lazy && h->prec() == PREC_F32) {
       auto L = std::make_shared<LazySrc>();
       L->mode = WSRC_SPADE; L->name = key + ".spade.modulate"; L->x = x; L->nx = nx; L->x_ups = x_ups; L->lrelu = act0;
@@ -1633,7 +1672,7 @@ struct Builder {
     if (!y1.lazy) tap(name + ".y1", y1);
     // learned shortcut (residual.py:98-108): its 1x1 convolution on SPADE_s(x) is fused into
     // conv_block_1's launch as extra K chunks accumulating into the same output tile
-    const bool fuse_s = learned && !getenv("RIB_NO_FUSE_SHORTCUT");
+    const bool fuse_s = learned && pol.fuse_shortcut;
     Act outs;
     if (learned && !fuse_s) {
       const ConvDef& cs = conv_of(h, name + ".conv_block_s");
@@ -1748,7 +1787,7 @@ struct Builder {
   // the plan (the label-only results rib_chain gathers into their slots before it runs the frame) are live from the
   // start, tapped activations (debug) until the end.
   bool assign_physical() {
-    const bool reuse = !getenv("RIB_NO_WS_REUSE") && !P->labels_only;
+    const bool reuse = pol.ws_reuse && !P->labels_only;
     if (!reuse) { P->ws_bytes = ws; return true; }
     bool bad = false;
     for (size_t i = 0; i < P->ops.size(); ++i)
@@ -1834,20 +1873,30 @@ struct Builder {
     return assign_physical();
   }
 
-  bool build() {
+  // ---- the frame plan, sub-network by sub-network (Generator.forward, PGNR/models/generator.py:181-234) ------------------
+  // Tensors that more than one sub-network touches.  The planners below run in the order of `build()`, which is the order
+  // of the launches AND of the workspace allocations (assign_physical() shares bytes by lifetime afterwards).
+  struct Frame {
+    Act L;                    // label map [B,22,H,W]: virtual (the caller's tensor, read in place by k_conv_lowc) or packed NHWC
+    Act Ein;                  // cat([img_fake, img_prev]) (generator.py:197): the embedder's input
+    Act I9;                   // cat([img_prev, img_fake, img]) (generator.py:232): the mask network's image input
+    std::vector<Act> cond;    // condition maps of the embedder, level 0 (full resolution) .. emb_down
+    Act CAT; Norm ncat;       // the mask network's concatenated encoder outputs [label | image] and their InstanceNorm
+    int chm = 0, Hm = 0, Wm = 0;
+  };
+
+  // boundary: NCHW user tensors -> NHWC (+concat, +zero channel padding), or nothing at all where k_conv_lowc reads them in place
+  bool plan_boundary(Frame& F) {
     const Cfg& g = h->g;
     const rib_config& c = g.c;
     const int H = P->H, W = P->W;
-    const int D = c.num_down_img;
-
-    // ---- boundary: NCHW user tensors -> NHWC (+concat, +zero channel padding) ----
     // Where the first layers can read the caller's NCHW tensors in place (k_conv_lowc) there is no packed copy at all
     const bool vL = lowc_serves({"down_first", "flow_network_temp.down_lbl.0"});
     const bool vE = lowc_serves({"ref_embedding.conv_first"});
     const bool vI = lowc_serves({"flow_network_temp.down_img.0"}) && head_without_nhwc(conv_of(h, "conv_img"));
-    Act L = vL ? virt(c.label_nc, H, W, U_LABEL, c.label_nc) : act(c.label_nc, H, W);
-    Act Ein = vE ? virt(c.image_nc * 2, H, W, U_FAKE, c.image_nc, U_PREV, c.image_nc) : act(c.image_nc * 2, H, W);     // cat([img_fake, img_prev]) generator.py:197
-    Act I9 = vI ? virt(c.image_nc * 3, H, W, U_PREV, c.image_nc, U_FAKE, c.image_nc, U_IMG, c.image_nc) : act(c.image_nc * 3, H, W);   // cat([img_prev, img_fake, img]) generator.py:232
+    F.L = vL ? virt(c.label_nc, H, W, U_LABEL, c.label_nc) : act(c.label_nc, H, W);
+    F.Ein = vE ? virt(c.image_nc * 2, H, W, U_FAKE, c.image_nc, U_PREV, c.image_nc) : act(c.image_nc * 2, H, W);     // cat([img_fake, img_prev]) generator.py:197
+    F.I9 = vI ? virt(c.image_nc * 3, H, W, U_PREV, c.image_nc, U_FAKE, c.image_nc, U_IMG, c.image_nc) : act(c.image_nc * 3, H, W);   // cat([img_prev, img_fake, img]) generator.py:232
     auto pack = [&](const std::string& nm, const Act& dst, int s0, int c0, int s1, int c1) {
       Op op; op.kind = OP_PACK; op.kclass = RIB_KC_PACK; op.name = nm;
       memset(&op.kp, 0, sizeof op.kp);
@@ -1857,19 +1906,27 @@ struct Builder {
       op.grid = dim3((H * W + 63) / 64, B, 1);
       push(op);
     };
-    if (L.Cp > 32 || Ein.Cp > 32 || I9.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }   // (Cp = 0 for the unpacked ones)
+    if (F.L.Cp > 32 || F.Ein.Cp > 32 || F.I9.Cp > 32) { error = "input channel counts above 32 are not supported by the pack kernel"; return false; }   // (Cp = 0 for the unpacked ones)
     mark_label = true;
-    if (!vL) pack("pack.label", L, U_LABEL, c.label_nc, 0, 0);
+    if (!vL) pack("pack.label", F.L, U_LABEL, c.label_nc, 0, 0);
     mark_label = false;
-    if (!vI) pack("pack.img9", I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
-    if (!vE) pack("pack.embed_in", Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
+    if (!vI) pack("pack.img9", F.I9, U_PREV, c.image_nc, U_FAKE, c.image_nc);           // cat([img_prev, img_fake, .]) generator.py:232
+    if (!vE) pack("pack.embed_in", F.Ein, U_FAKE, c.image_nc, U_PREV, c.image_nc);      // cat([img_fake, img_prev]) generator.py:197
 
-    // ---- ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) ----
-    std::vector<Act> cond(c.emb_down + 1);
+    return true;
+  }
+
+  // ref_embedding (LabelEmbedder 'encoder', generator.py:360-387) + gamma/beta of the SPADEs of the small condition levels
+  bool plan_embedder(Frame& F) {
+    const Cfg& g = h->g;
+    const rib_config& c = g.c;
+    const int H = P->H, W = P->W;
+    std::vector<Act>& cond = F.cond;
+    cond.assign(c.emb_down + 1, Act());
     {
       const ConvDef& cf = conv_of(h, "ref_embedding.conv_first");
       cond[0] = act(cf.cout, H, W);
-      ConvArgs a; a.cd = &cf; a.in = Ein; a.out = cond[0]; a.act = ACT_LRELU;
+      ConvArgs a; a.cd = &cf; a.in = F.Ein; a.out = cond[0]; a.act = ACT_LRELU;
       if (!conv(a, "ref_embedding.conv_first")) return false;
       tap("cond_0", cond[0]);
       for (int i = 0; i < c.emb_down; ++i) {
@@ -1884,31 +1941,48 @@ struct Builder {
     for (int j = 0; j <= c.emb_down; ++j)
       if (!cond_level_gemm(j, cond[j])) return false;
 
-    // ---- label branch of the mask network (depends only on the label map) ----
-    const std::string m = "flow_network_temp";
-    const int chm = g.mask_nf(c.mask_down);
-    const int Hm = H >> c.mask_down, Wm = W >> c.mask_down;
+    return true;
+  }
+
+  // label encoder of the mask network: depends only on the label map, so a chain runs it once per segment (labels-only plan);
+  // in a paired frame plan it rides with the image encoder instead (plan_mask_net)
+  bool plan_mask_label_branch(Frame& F) {
+    const Cfg& g = h->g;
+    const rib_config& c = g.c;
+    const int H = P->H, W = P->W;
+    F.chm = g.mask_nf(c.mask_down);
+    F.Hm = H >> c.mask_down; F.Wm = W >> c.mask_down;
+    const int chm = F.chm;
     if (h->padc(chm) != chm) { error = "mask network width must be a multiple of 8 (16 with bf16 storage)"; return false; }
-    Act CAT = act(2 * chm, Hm, Wm);
-    Norm ncat = norm(CAT.Cp);
+    F.CAT = act(2 * chm, F.Hm, F.Wm);
+    F.ncat = norm(F.CAT.Cp);
     if (!pair_mask) {
       mark_label = true;
-      if (!mask_branch(0, L, CAT, ncat, chm)) return false;
+      if (!mask_branch(0, F.L, F.CAT, F.ncat, chm)) return false;
       mark_label = false;
     }
 
-    // ---- main generator (generator.py:201-228) ----
+    return true;
+  }
+
+  // main generator (generator.py:201-228): down_first, down_0..D with AvgPool, res blocks, up_D..0, conv_img + tanh
+  bool plan_trunk(Frame& F) {
+    const Cfg& g = h->g;
+    const rib_config& c = g.c;
+    const int H = P->H, W = P->W;
+    const int D = c.num_down_img;
+    const std::vector<Act>& cond = F.cond;
     Act x; Norm nx;
     {
       const ConvDef& df = conv_of(h, "down_first");
       x = act(df.cout, H, W); nx = norm(x.Cp);
-      ConvArgs a; a.cd = &df; a.in = L; a.out = x; a.want_stats = true; a.stats_out = &nx;
+      ConvArgs a; a.cd = &df; a.in = F.L; a.out = x; a.want_stats = true; a.stats_out = &nx;
       mark_label = true;
       if (!conv(a, "down_first")) return false;
       mark_label = false;
       tap("down_first", x);
     }
-    record_label_slots(x, nx, CAT, ncat);
+    record_label_slots(x, nx, F.CAT, F.ncat);
     for (int i = 0; i <= D; ++i) {
       Act out; Norm nout;
       const bool last = (i == D);
@@ -1952,14 +2026,25 @@ struct Builder {
     }
     {   // conv_img 'AC' + tanh (generator.py:114-116,228); also lands in img9[6:9]
       const ConvDef& ci = conv_of(h, "conv_img");
-      ConvArgs a; a.cd = &ci; a.in = x; a.pro_lrelu = true; a.out = I9; a.yoff = c.image_nc * 2;
+      ConvArgs a; a.cd = &ci; a.in = x; a.pro_lrelu = true; a.out = F.I9; a.yoff = c.image_nc * 2;
       a.cout_store = c.image_nc; a.act = ACT_TANH; a.y_nchw = US(U_IMG);
-      a.y_none = I9.virt;      // the mask network then reads the image from the caller's NCHW tensor
+      a.y_none = F.I9.virt;      // the mask network then reads the image from the caller's NCHW tensor
       if (!conv(a, "conv_img")) return false;
     }
 
-    // ---- MaskGenerator (generator.py:493-510): image branch, then join with the label branch ----
-    if (pair_mask ? !mask_branches_paired(L, I9, CAT, ncat, chm) : !mask_branch(1, I9, CAT, ncat, chm)) return false;
+    return true;
+  }
+
+  // MaskGenerator (generator.py:493-510): image encoder (paired with the label encoder where the plan pairs), join with the
+  // label branch, res_flow blocks, phase-convolution decoder, sigmoid head (+ the driver's blend)
+  bool plan_mask_net(Frame& F) {
+    const Cfg& g = h->g;
+    const rib_config& c = g.c;
+    const int H = P->H, W = P->W;
+    const std::string m = "flow_network_temp";
+    const int chm = F.chm, Hm = F.Hm, Wm = F.Wm;
+    const Act& CAT = F.CAT; const Norm& ncat = F.ncat;
+    if (pair_mask ? !mask_branches_paired(F.L, F.I9, CAT, ncat, chm) : !mask_branch(1, F.I9, CAT, ncat, chm)) return false;
     tap("mask.cat.raw", CAT);
     Act r; bool first = true;
     for (int i = 0; i < c.mask_res_blocks; ++i) {
@@ -1989,7 +2074,7 @@ struct Builder {
       {
         // the join feeds the next block's conv_block_0 (no prologue): when that runs in the Winograd domain its input
         // transform computes the join on the fly and stores it
-        static const bool no_lazy = getenv("RIB_NO_LAZY") != nullptr;
+        const bool no_lazy = !pol.lazy_sources;
         ConvArgs t;
         if (i + 1 < c.mask_res_blocks) t.cd = &conv_of(h, m + ".res_flow." + std::to_string(i + 1) + ".conv_block_0");
         if (t.cd && !no_lazy && h->prec() == PREC_F32 && runs_wino(t, Hm, Wm) && t.cd->cinp == o.Cp && n1.ld == o.Cp) {
@@ -2036,7 +2121,12 @@ struct Builder {
       a.act = ACT_SIGMOID; a.y_user = US(U_MASK);
       if (!conv(a, cm.name)) return false;
     }
-    return assign_physical();
+    return true;
+  }
+
+  bool build() {
+    Frame F;
+    return plan_boundary(F) && plan_embedder(F) && plan_mask_label_branch(F) && plan_trunk(F) && plan_mask_net(F) && assign_physical();
   }
 };
 
@@ -2045,8 +2135,7 @@ struct Builder {
 // level by level at batch 1 (Builder::mask_branches_paired) - same kernels, same choices, bit-identical frames.
 enum { PLAN_LABELS = 1, PLAN_UNPAIRED = 2 };
 inline bool plan_pairs(int B, int flags) {
-  static const bool off = getenv("RIB_NO_PAIR") != nullptr;
-  return !off && B == 1 && !(flags & (PLAN_LABELS | PLAN_UNPAIRED));
+  return FusionPolicy().pair_mask_encoders && B == 1 && !(flags & (PLAN_LABELS | PLAN_UNPAIRED));
 }
 Plan* get_plan(rib_handle* h, int B, int H, int W, int flags = 0, int tuneB = 0) {
   const bool labels_only = (flags & PLAN_LABELS) != 0;
@@ -2984,8 +3073,7 @@ int rib_debug_spade_weight(rib_handle* h, const char* conv_name, float* w_2c_by_
 }
 
 // Launch list of a plan, for the CPU-side structure tests: "<name>|<kernel class>|<grid>|<tile>"
-namespace {
-int rib_debug_launch_info_head(const Op& op, char* buf, size_t buflen) {
+static int launch_info_head(const Op& op, char* buf, size_t buflen) {
   if (op.kind == OP_IGEMM && op.small_co > 0)
     snprintf(buf, buflen, "%s|%d|%u,%u,%u|%s 16x16 tile, %d output channels%s|%.0f", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z,
              op.head ? "head (taps as MFMA columns)" : "direct (vector ALUs)", op.small_co, op.fuse_blend ? " + fused blend" : "", op.flops);
@@ -3003,13 +3091,11 @@ int rib_debug_launch_info_head(const Op& op, char* buf, size_t buflen) {
     snprintf(buf, buflen, "%s|%d|%u,%u,%u||0", op.name.c_str(), op.kclass, op.grid.x, op.grid.y, op.grid.z);
   return RIB_OK;
 }
-}  // namespace
 
-namespace {
 // Algorithmic HBM bytes of one launch (tools/prof_ops.py prices every launch against max(FLOPs / MFMA peak, these bytes / HBM)):
 // every operand the launch NEEDS read once, every result written once - activations in the storage type, filters and
 // statistics as stored; halo re-reads, split-K re-reads and L2 misses are exactly what this leaves out.
-double op_algorithmic_bytes(const rib_handle* h, const Plan* P, const Op& op) {
+static double op_algorithmic_bytes(const rib_handle* h, const Plan* P, const Op& op) {
   const double e = h->esz(), Bn = P->B;
   switch (op.kind) {
     case OP_IGEMM: {
@@ -3069,14 +3155,13 @@ double op_algorithmic_bytes(const rib_handle* h, const Plan* P, const Op& op) {
     default: return 0.0;
   }
 }
-}  // namespace
 
 int rib_debug_launch_info(rib_handle* h, int B, int H, int W, int idx, char* buf, size_t buflen) {
   if (!h || !buf) return RIB_ERR_INVALID;
   Plan* P = get_plan(h, B, H, W);
   if (!P || idx < 0 || idx >= (int)P->ops.size()) return RIB_ERR_INVALID;
   const Op& op = P->ops[idx];
-  const int rc = rib_debug_launch_info_head(op, buf, buflen);
+  const int rc = launch_info_head(op, buf, buflen);
   const size_t n = strlen(buf);
   if (n + 24 < buflen) snprintf(buf + n, buflen - n, "|%.0f", op_algorithmic_bytes(h, P, op));
   return rc;
