@@ -2551,17 +2551,28 @@ int rib_finalize_weights(rib_handle* h) {
   }
   if (h->mc16()) {
     // rows of `rowlen` K-contiguous elements: [row][rowlen] bf16
-    auto to16 = [&](size_t src, size_t dst, size_t rows, size_t rowlen) {
+    // IEEE half ends at 65504: a folded filter beyond it (a trained checkpoint's W / sigma can be far larger than the seed-defined
+    // ones the mode was developed on) would become an infinity in the 16-bit copy and a NaN frame later - refuse it HERE, by name
+    std::string out_of_range;
+    auto to16 = [&](const std::string& name, size_t src, size_t dst, size_t rows, size_t rowlen) {
       uint16_t* d = reinterpret_cast<uint16_t*>(&blob[dst]);
-      if (h->prec() == PREC_F16) for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_f16(blob[src + i]);
-      else for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_bf16(blob[src + i]);
+      if (h->prec() == PREC_F16) {
+        for (size_t i = 0; i < rows * rowlen; ++i) {
+          const float v = blob[src + i];
+          if (!(std::fabs(v) <= 65504.f) && out_of_range.empty()) out_of_range = fmt("%s: folded filter value %g", name.c_str(), (double)v);
+          d[i] = host_f16(v);
+        }
+      } else for (size_t i = 0; i < rows * rowlen; ++i) d[i] = host_bf16(blob[src + i]);
     };
     for (auto& c : h->convs) {
       if (!c.used) continue;
-      to16(c.w_off, c.w16_off, (size_t)c.coutp * c.ks * c.ks, c.cinp);      // a "row" is one (output channel, tap) slice
-      if (c.ups_in) to16(c.wp_off, c.wp16_off, (size_t)c.coutp * 16, c.cinp);
+      to16(c.name, c.w_off, c.w16_off, (size_t)c.coutp * c.ks * c.ks, c.cinp);      // a "row" is one (output channel, tap) slice
+      if (c.ups_in) to16(c.name, c.wp_off, c.wp16_off, (size_t)c.coutp * 16, c.cinp);
     }
-    for (auto& sg : h->spades) to16(sg.w_off, sg.w16_off, sg.npad, h->padc(sg.cond));
+    for (auto& sg : h->spades) to16(sg.key, sg.w_off, sg.w16_off, sg.npad, h->padc(sg.cond));
+    if (!out_of_range.empty())
+      return fail(h, RIB_ERR_INVALID, "rib_finalize_weights: " + out_of_range + " is outside IEEE half's range (65504): this checkpoint cannot run in "
+                                      "RIB_DTYPE_F16; use RIB_DTYPE_BF16 (same speed, fp32's range) or RIB_DTYPE_F32");
   }
   if (h->device < 0) {
     h->host_blob.swap(blob);

@@ -143,7 +143,26 @@ class Generator:
         with torch.cuda.device(self.device):
             _native.check(self._h, self._lib.rib_finalize_weights(self._h))
         self.weights_version += 1
+        if self.compute_dtype == "f16":
+            self.assert_finite_probe()
         return self
+
+    def assert_finite_probe(self, size=64, seed=0):
+        """IEEE half ends at 65504.  rib_finalize_weights refuses a checkpoint whose FOLDED FILTERS leave that range; this
+        checks the ACTIVATIONS: one small forward on full-range inputs (frames uniform in [-1, 1], label maps in their value
+        ranges) must come out finite - the condition encoder is five convolutions with no normalisation between them, the one
+        place where a trained checkpoint's larger filters can compound.  Raises FloatingPointError (the f16 mode must fail
+        loudly, not render NaN frames); called by load_state_dict in the f16 mode."""
+        m = 1 << max(self.spec.num_down_img + 1, self.spec.mask_down, self.spec.emb_down)
+        hw = max(size // m, 1) * m
+        g = torch.Generator().manual_seed(seed)
+        label = torch.cat([torch.rand(1, 3, hw, hw, generator=g) * 2 - 1, torch.rand(1, self.spec.label_nc - 3, hw, hw, generator=g)], dim=1)
+        fake, prev = torch.rand(1, self.spec.image_nc, hw, hw, generator=g) * 2 - 1, torch.rand(1, self.spec.image_nc, hw, hw, generator=g) * 2 - 1
+        img, mask = self(label.to(self.device), None, fake.to(self.device), prev.to(self.device))
+        if not (bool(torch.isfinite(img).all()) and bool(torch.isfinite(mask).all())):
+            raise FloatingPointError("compute_dtype='%s': this checkpoint's activations leave the 16-bit format's range (non-finite output on "
+                                     "a %dx%d probe frame); use compute_dtype='bf16' (same speed, fp32's range) or 'f32'" % (self.compute_dtype, hw, hw))
+        return True
 
     # ---- multi-GPU weight hand-off (one RCCL broadcast of the folded blob) -----------------
     def export_weights(self) -> torch.Tensor:

@@ -223,7 +223,7 @@ def test_warp_extension_matches_grid_sample():
         assert float((out - ref).abs().max()) <= 5e-5, (B, H, W, amp)
     # zero flow is the identity (up to the fp32 un-normalisation of the sampling grid)
     assert float((G.warp(img, torch.zeros_like(flow)).cpu() - img).abs().max()) <= 1e-4
-    # eight channels (the most rib_warp takes: 34 KB of staged window)
+    # eight channels (the most rib_warp takes: 8 x 16 KB = 126 KB of staged window in dynamic LDS)
     img8 = torch.rand(1, 8, 96, 160, generator=torch.Generator().manual_seed(9)) * 2 - 1
     flow8 = (torch.rand(1, 2, 96, 160, generator=torch.Generator().manual_seed(10)) - 0.5) * 10
     ys, xs = torch.meshgrid(torch.linspace(-1, 1, 96), torch.linspace(-1, 1, 160), indexing="ij")
@@ -456,6 +456,69 @@ def test_driver_pipeline_stages_can_be_driven_one_at_a_time(tmp_path):
 F16_MAX, F16_MEAN = 2.6e-2, 2e-3      # = 1.5 x measured (1.7e-2 worst max, 1.3e-3 worst mean over the sizes and the 32-frame chain)
 
 
+def _assert_on_rounding_model(spec, sd, inputs, fmt, got):
+    """The 16-bit bounds are model-derived (round 6): oracle/precision_model.py applies the format's roundings where the kernels
+    apply them; the GPU error must sit on it - mean within 20 %, max (a tail statistic) within a factor 1.6.  The constants
+    above stay as a tripwire.  tests/test_precision_model.py makes the same comparison on the CPU against the committed figures."""
+    from oracle import precision_model
+    m = precision_model.predict(spec, sd, *inputs, fmt=fmt)
+    for k in ("mean_abs_img", "mean_abs_mask"):
+        assert 0.8 <= got[k] / m[k] <= 1.2, (fmt, k, got[k], m[k])
+    for k in ("max_abs_img", "max_abs_mask"):
+        assert 1 / 1.6 <= got[k] / m[k] <= 1.6, (fmt, k, got[k], m[k])
+
+
+def _scaled_checkpoint(sd, s):
+    """The same checkpoint with every FOLDED filter s times larger (what a trained checkpoint may bring: SURVEY f-3):
+    spectral-norm convolutions through their u vector (W / (u . W v) grows by s when u shrinks by s), the others directly."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_u"):
+            out[k] = v / s
+        elif k.endswith(".layers.conv.weight"):
+            out[k] = v * s
+        else:
+            out[k] = v
+    return out
+
+
+def test_half_mode_stays_finite_or_fails_loudly_on_larger_filters():
+    """DESIGN 6 admitted that the half mode's range argument had only seen He-scaled synthetic filters.  Folded filters 4x and
+    16x larger: the mode either renders finite frames or REFUSES the checkpoint when it is loaded (rib_finalize_weights checks
+    the folded filters against 65504, Generator.load_state_dict runs a full-range probe frame) - it never hands out NaN
+    frames silently.  bf16 (fp32's exponent range) and fp32 take the same checkpoints and agree with the oracle."""
+    cfg = rib.hsm_gen_config()
+    spec = rib.GenSpec.from_cfg(cfg)
+    sd0 = synth.make_state_dict(spec, 0)
+    label, fake, prev = synth.make_inputs(spec, 1, 128, 128, 9)
+    outcome = {}
+    for s in (4.0, 16.0, 4096.0):
+        sd = _scaled_checkpoint(sd0, s)
+        oimg, omask = oracle(spec, sd)(label, None, fake, prev)
+        assert bool(torch.isfinite(oimg).all())
+        G32 = rib.Generator(cfg).eval(); G32.load_state_dict(sd)
+        i32, m32 = G32(label, None, fake, prev)
+        assert float((i32.cpu() - oimg).abs().max()) <= 5e-4 and float((m32.cpu() - omask).abs().max()) <= 5e-4, s      # (larger values, same relative error)
+        Gb = rib.Generator(cfg, compute_dtype="bf16").eval(); Gb.load_state_dict(sd)
+        ib, mb = Gb(label, None, fake, prev)
+        assert bool(torch.isfinite(ib).all()) and bool(torch.isfinite(mb).all()), s
+        Gh = rib.Generator(cfg, compute_dtype="f16").eval()
+        try:
+            Gh.load_state_dict(sd)
+        except (FloatingPointError, Exception) as e:      # noqa: BLE001
+            from render_in_between_amd import _native
+            assert isinstance(e, (FloatingPointError, _native.RibError)), repr(e)
+            assert "range" in str(e), str(e)
+            outcome[s] = "refused: " + type(e).__name__
+            continue
+        ih, mh = Gh(label, None, fake, prev)
+        assert bool(torch.isfinite(ih).all()) and bool(torch.isfinite(mh).all()), s
+        outcome[s] = "finite, img max-abs %.2e" % float((ih.cpu() - oimg).abs().max())
+    with open("gpurun_out/f16_range_stress.json", "w") as f:
+        json.dump({str(k): v for k, v in outcome.items()}, f, indent=1)
+    assert outcome[4096.0].startswith("refused")          # 0.4 x 4096 is far inside half's range, the activations it drives are not
+
+
 def test_half_storage_mode_meets_its_bound():
     """RIB_DTYPE_F16: the 16-bit storage layouts and kernels of the bf16 mode with IEEE half elements
     (v_mfma_f32_32x32x16_f16).  Same bytes, same launches, 8x smaller rounding unit: the CPU model of the roundings
@@ -477,6 +540,8 @@ def test_half_storage_mode_meets_its_bound():
              "mean_abs_img": float((img.cpu() - oimg).abs().mean()), "mean_abs_mask": float((mask.cpu() - omask).abs().mean())}
         rep["%dx%dx%d" % (B, H, W)] = r
         assert r["max_abs_img"] <= F16_MAX and r["max_abs_mask"] <= F16_MAX and r["mean_abs_img"] <= F16_MEAN and r["mean_abs_mask"] <= F16_MEAN, (B, H, W, r)
+        if H <= 256:      # the bound that means something: the kernels sit on the CPU model of the format's roundings
+            _assert_on_rounding_model(spec, sd, (label, fake, prev), "f16", r)
     with open("gpurun_out/parity_f16.json", "w") as f:
         json.dump(rep, f)
     label, fake, prev = synth.make_inputs(spec, 1, 64, 64, 5)
@@ -518,6 +583,7 @@ def test_bf16_storage_mode_error_is_bounded():
         if H >= 48:      # (a 1x1 deepest map makes InstanceNorm degenerate: compared loosely in fp32 too)
             # measured (round 3): img 9.6e-2 / 1.10e-1 max, 8.2e-3 / 9.9e-3 mean; mask 2.8e-2 / 3.0e-2 max, 3.6e-3 / 4.0e-3 mean
             assert d_img <= 1.7e-1 and d_mask <= 4.5e-2 and m_img <= 1.5e-2 and m_mask <= 6e-3, (B, H, W, d_img, d_mask, m_img, m_mask)
+            _assert_on_rounding_model(spec, sd, (label, fake, prev), "bf16", rep["%dx%dx%d" % (B, H, W)])
         assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(mask).all())
     with open("gpurun_out/parity_bf16_256.json", "w") as f:
         json.dump(rep, f)

@@ -296,10 +296,11 @@ def test_every_kernel_variant_of_the_library_is_used_by_some_plan(lib):
     sys.path.insert(0, ROOT)
     from tools.variant_usage import usage
     info, used = usage()
-    unused = [i for i, (prec, g) in enumerate(info) if i not in used and g[0] != 0]
-    # (a handful fall out of use when a table is re-measured, and a candidate added for a tuning run is unused until a table picks it:
-    #  ADVICE r04 - a warning up to 16 entries, so that the autotuner's search space can be widened without editing this test)
-    if len(unused) > 4:
-        import warnings
-        warnings.warn("%d kernel variants of the library are launched by no plan of the sweep: %s" % (len(unused), [info[i] for i in unused][:6]))
-    assert len(unused) <= 16, [info[i] for i in unused]
+    unused = [tuple(info[i][1]) + (info[i][0],) for i in range(len(info)) if i not in used and info[i][1][0] != 0]
+    # Candidates added for a tuning run are unused until a table picks them: they are listed HERE, by geometry (+ precision), so
+    # that widening the autotuner's search space is an explicit edit and anything else that falls out of use fails the test
+    # (the limit had been relaxed to 16 with a warning - a dozen orphans would have passed silently).
+    EXPECTED_UNUSED = set()          # currently none: round 6's 32x16-tile candidates lost and were removed again
+    stray = [g for g in unused if g not in EXPECTED_UNUSED]
+    assert not stray, "kernel variants launched by no plan of the sweep (prune them or list them as tuning candidates): %s" % stray
+    assert EXPECTED_UNUSED <= set(unused), "listed as unused but launched: %s" % sorted(EXPECTED_UNUSED - set(unused))
