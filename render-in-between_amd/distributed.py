@@ -66,7 +66,39 @@ def self_launch(script: str, argv: Sequence[str], nproc: int) -> int:
     are fresh processes, nothing re-executes after HIP has been initialised.  Rank 0's stdout is the caller's."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
-    return subprocess.call(launch_command(script, argv, nproc), env=env)
+    rc = subprocess.call(launch_command(script, argv, nproc), env=env)
+    if rc != 0:
+        print("[rib launcher] %d ranks of %s ended with exit code %d (HSA_ENABLE_IPC_MODE_LEGACY=%s); the failing rank's own line starts "
+              "with '[rib rank' above" % (nproc, os.path.basename(script), rc, env["HSA_ENABLE_IPC_MODE_LEGACY"]), file=sys.stderr, flush=True)
+    return rc
+
+
+@contextlib.contextmanager
+def startup_phase(what: str, device_index: int = None):
+    """Makes a failure of the multi-GPU start-up self-diagnosing (RCCL has only ever run in a world of
+    one rank on the build's boxes, so the first real 8-GPU run must say what went wrong by itself).  Any exception inside
+    the block - process-group creation, the first communicator, the weight broadcast - is reported on stderr as ONE line
+    that names the rank, its device, the backend, the RCCL / HIP error text and the IPC mode in force, and is then re-raised:
+    the rank exits non-zero, torch.distributed.run ends the other ranks, and self_launch (a parent that never touched the
+    GPU) hands the code back."""
+    try:
+        yield
+    except BaseException as e:      # noqa: BLE001 (reported and re-raised)
+        print(failure_line(what, e, device_index), file=sys.stderr, flush=True)
+        raise
+
+
+def failure_line(what: str, exc: BaseException, device_index: int = None) -> str:
+    env = os.environ
+    idx = rank_device_index() if device_index is None else device_index
+    backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else env.get("RIB_DIST_BACKEND", "nccl (RCCL)" if torch.cuda.is_available() else "gloo")
+    ident = device_identity(idx) if torch.cuda.is_available() else "cuda:%d (no GPU visible)" % idx
+    msg = " ".join(str(exc).split())[:400] or type(exc).__name__
+    return ("[rib rank %s/%s local_rank %s] FAILED during %s | device %s | backend %s | HSA_ENABLE_IPC_MODE_LEGACY=%s (0 = dmabuf IPC, what this "
+            "host driver supports) NCCL_DEBUG=%s MASTER=%s:%s | %s: %s"
+            % (env.get("RANK", "0"), env.get("WORLD_SIZE", "1"), env.get("LOCAL_RANK", "0"), what, ident, backend,
+               env.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset"), env.get("NCCL_DEBUG", "unset"), env.get("MASTER_ADDR", "?"), env.get("MASTER_PORT", "?"),
+               type(exc).__name__, msg))
 
 
 def is_rank_process() -> bool:
@@ -100,7 +132,7 @@ def init_process_group(backend: str = None, device: torch.device = None):
     # boxes, a five-line banner - and stdout belongs to the callers' results (bench.py: ONE JSON line).  The environment is
     # left as the user set it (NCCL_DEBUG, NCCL_DEBUG_FILE); instead file descriptor 1 points at stderr while the group
     # and its first communicator are created (a one-element all-reduce forces the latter), and is restored afterwards.
-    with _stdout_to_stderr():
+    with _stdout_to_stderr(), startup_phase("init_process_group(%s) + first communicator" % backend, getattr(kw.get("device_id"), "index", None)):
         dist.init_process_group(backend=backend, **kw)
         t = torch.zeros(1, dtype=torch.int32, device=kw.get("device_id", "cpu"))
         dist.all_reduce(t)
@@ -160,18 +192,19 @@ def broadcast_weights(gen, src: int = 0) -> float:
     needs on its own device - 188 MB in the 16-bit modes) and adopts it (rib_import_weights checks the blob's header: mode and layout must match).
     Returns the broadcast wall time in ms (synchronised)."""
     rank = dist.get_rank()
-    if rank == src:
-        buf = gen.export_weights()
-    else:
-        buf = torch.empty(gen.weights_numel(), dtype=torch.float32, device=gen.device)
-    torch.cuda.synchronize(gen.device)
-    t0 = time.perf_counter()
-    broadcast_blob(buf, src)
-    torch.cuda.synchronize(gen.device)
-    ms = (time.perf_counter() - t0) * 1e3
-    if rank != src:
-        gen.import_weights(buf)
+    with startup_phase("the weight broadcast (one %s broadcast of the folded blob from rank %d)" % (dist.get_backend(), src), getattr(gen.device, "index", None)):
+        if rank == src:
+            buf = gen.export_weights()
+        else:
+            buf = torch.empty(gen.weights_numel(), dtype=torch.float32, device=gen.device)
         torch.cuda.synchronize(gen.device)
+        t0 = time.perf_counter()
+        broadcast_blob(buf, src)
+        torch.cuda.synchronize(gen.device)
+        ms = (time.perf_counter() - t0) * 1e3
+        if rank != src:
+            gen.import_weights(buf)
+            torch.cuda.synchronize(gen.device)
     return ms
 
 

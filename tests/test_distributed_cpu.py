@@ -1,6 +1,8 @@
 """Multi-process CPU coverage of the N>1 path (gloo, world_size 2): the static unit partition and the
 single weight-blob broadcast that the multi-GPU bench performs over RCCL."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -232,3 +234,34 @@ def test_a_failure_on_rank0_ends_every_rank_before_the_broadcast():
         assert p.exitcode == 0
     assert res[0] == ["rank 0 could not load the checkpoint"]
     assert res[1] == ["another rank failed: rank 0 could not load the checkpoint"]
+
+
+def test_a_failed_start_up_names_rank_device_backend_and_ipc_mode(monkeypatch, capfd, tmp_path):
+    """the first real multi-GPU run must diagnose itself.  A failure inside the start-up phases (process
+    group + first communicator, the weight broadcast) prints ONE line with the rank, its device, the backend, the error text
+    and the IPC mode in force, then propagates; the launcher - a parent that never touched the GPU - reports the exit code
+    of its ranks and hands it back."""
+    from render_in_between_amd import distributed as ribdist
+    for k, v in (("RANK", "5"), ("WORLD_SIZE", "8"), ("LOCAL_RANK", "5"), ("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29400")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("RIB_BENCH_DEVICE", raising=False)
+    with pytest.raises(RuntimeError, match="unhandled system error"):
+        with ribdist.startup_phase("init_process_group(nccl) + first communicator"):
+            raise RuntimeError("NCCL error in: ProcessGroupNCCL.cpp:2000, unhandled system error\nhipIpcGetMemHandle: invalid argument")
+    err = capfd.readouterr().err.strip().splitlines()
+    assert len(err) == 1, err
+    line = err[0]
+    for piece in ("[rib rank 5/8 local_rank 5]", "init_process_group(nccl) + first communicator", "device cuda:5", "HSA_ENABLE_IPC_MODE_LEGACY=0",
+                  "MASTER=127.0.0.1:29400", "RuntimeError: NCCL error in", "hipIpcGetMemHandle: invalid argument"):
+        assert piece in line, (piece, line)
+    # nothing is printed when nothing fails
+    with ribdist.startup_phase("the weight broadcast"):
+        pass
+    assert capfd.readouterr().err == ""
+    # the launcher: a fresh child per rank; a non-zero exit is reported on stderr and returned, stdout stays the ranks'
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\nprint('line of rank', os.environ['RANK'])\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    rc = ribdist.self_launch(str(script), [], 2)
+    out = capfd.readouterr()
+    assert rc != 0 and "[rib launcher] 2 ranks of rank.py ended with exit code" in out.err and "HSA_ENABLE_IPC_MODE_LEGACY=0" in out.err
+    assert "line of rank 0" in out.out

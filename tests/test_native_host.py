@@ -209,6 +209,29 @@ def test_precision_mode_switch_refolds_the_weights(lib):
     lib.rib_destroy(h)
 
 
+def test_half_mode_refuses_filters_beyond_its_range_and_products_setting_is_checked(lib):
+    """IEEE half ends at 65504: rib_finalize_weights in RIB_DTYPE_F16 refuses a checkpoint whose FOLDED filter leaves that range
+    (it would become an infinity in the 16-bit copy and a NaN frame later) and names the layer; bf16 and fp32 take the same
+    tensors.  rib_set_products accepts exactly its two settings."""
+    cfg = rib.hsm_gen_config(**MID_CFG)
+    spec, h = host_handle(lib, cfg)
+    sd = synth.make_state_dict(spec, 5)
+    sd["conv_img.layers.conv.weight"] = sd["conv_img.layers.conv.weight"] * 1e6          # (no spectral norm on this layer: folded = stored)
+    for k, v in sd.items():
+        t = v.contiguous()
+        d = (C.c_int64 * t.dim())(*t.shape)
+        assert lib.rib_set_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), d) == 0
+    assert lib.rib_finalize_weights(h) == 0                                                  # fp32: fine
+    assert lib.rib_set_compute_dtype(h, 1) == 0                                              # bf16 (fp32's exponent range): fine
+    assert lib.rib_set_compute_dtype(h, 3) != 0                                              # half: refused, by name
+    msg = lib.rib_last_error(h).decode()
+    assert "conv_img" in msg and "65504" in msg and "RIB_DTYPE_BF16" in msg, msg
+    assert lib.rib_set_compute_dtype(h, 0) == 0 and lib.rib_workspace_bytes(h, 1, 64, 64) > 0   # the handle is still usable in another mode
+    assert lib.rib_set_products(h, 1) == 0 and lib.rib_set_products(h, 0) == 0
+    assert lib.rib_set_products(h, 2) != 0 and lib.rib_set_products(None, 0) != 0
+    lib.rib_destroy(h)
+
+
 def test_plan_flops_and_shape_rules(lib):
     spec, h = host_handle(lib, rib.hsm_gen_config())
     fl = (C.c_double * len(_native.KC_NAMES))()
