@@ -37,12 +37,22 @@ class MotionSpec:
             pg = (lambda k, d: pe.get(k, d)) if isinstance(pe, dict) else (lambda k, d: getattr(pe, k, d))
             kind = pg("position_embedding", "v2")
             if kind not in ("v2", "sine"):
-                raise ValueError("position_embedding '%s' is not supported (only the sine encoding 'v2')" % kind)
+                # 'v3' / 'learned' (HMM/models/position_encoding.py:55-90) is an nn.Embedding(160, hidden_dim) that the reference
+                # creates in Trainer.__init__ (models/trainer.py:64) and never restores: load_state_dict is called on the
+                # transformer alone (:74) and inference hands over trainer.pos_encode as constructed (inference.py:67).  At
+                # inference its table is therefore fresh uniform noise, different in every process: there is no defined result
+                # to reproduce, so the variant is refused instead of built.
+                raise ValueError("position_embedding '%s' is not supported: only the sine encoding 'v2' is defined at inference (the reference "
+                                 "never saves or loads the learned table, so its inference would add fresh random noise to every token)" % kind)
             pos_dim = int(pg("hidden_dim", tg("hidden_dim", 128)))
         else:
             pos_dim = int(tg("hidden_dim", 128))
         if tg("intermediate", False):
-            raise ValueError("transformer.intermediate=True (stack of decoder activations) is not supported")
+            # return_intermediate_dec (HMM/models/transformer.py:162-196) makes the decoder return the STACK of its layers' outputs
+            # [layers, L, N, C] for the training losses; the reference's own inference then fails on it (inference.py:
+            # `pred.permute(1, 2, 0)` of a 4-D tensor), so the inference path this package replaces never runs with it
+            raise ValueError("transformer.intermediate=True is a training-time option (the decoder returns the stack of its layers' outputs, "
+                             "which the reference's own inference cannot consume either); set it to False for inference")
         s = MotionSpec(input_joints=int(tg("input_joints", 38)), hidden_dim=int(tg("hidden_dim", 128)),
                        nheads=int(tg("nheads", 8)), dim_feedforward=int(tg("dim_feedforward", 256)),
                        enc_layers=int(tg("enc_layers", 6)), dec_layers=int(tg("dec_layers", 6)),
