@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerate the measured artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r05
+#   bash tools/refresh_profiles.sh r06
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); from render_in_between_amd import _native; b = _native.build_info(); print(b['stamp'], b['raw'])" > $OUT/${TAG}_build_stamp.txt
 echo "[refresh] bench (default command)"; python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[refresh] rocprofv3 --stats of the bench command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_prof.log 2>&1
 cp $OUT/prof_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 echo "[refresh] per-op table"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_prof_ops.log 2>&1
@@ -23,6 +23,12 @@ python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_320 --height 320 --width 
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops_b4 -- python3 $ROOT/tools/prof_ops.py --run --batch 4 > $OUT/${TAG}_prof_ops_b4.log 2>&1
 python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_b4 --batch 4 > $OUT/${TAG}_prof_ops_512_b4.txt
 rm -rf $OUT/prof_ops_320 $OUT/prof_ops_b4
+echo "[refresh] per-op tables of the bf16 frame and of the opt-in split-product setting (the roof columns price the 16-bit frame against HBM)"
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops_bf16 -- python3 $ROOT/tools/prof_ops.py --run --dtype bf16 > $OUT/${TAG}_prof_ops_bf16.log 2>&1
+python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_bf16 --dtype bf16 > $OUT/${TAG}_prof_ops_512_bf16.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_ops_x3 -- python3 $ROOT/tools/prof_ops.py --run --products bf16x3 > $OUT/${TAG}_prof_ops_x3.log 2>&1
+python3 $ROOT/tools/prof_ops.py --report $OUT/prof_ops_x3 > $OUT/${TAG}_prof_ops_512_x3.txt
+rm -rf $OUT/prof_ops_bf16 $OUT/prof_ops_x3
 echo "[refresh] PMC passes (separate runs, kernel trace only)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/tools/prof_ops.py --run > $OUT/${TAG}_pmc_w.log 2>&1
@@ -43,6 +49,23 @@ for flags in "--height 320 --width 480" "--height 320 --width 480 --no-tuning" "
   echo "## $flags" >> $OUT/${TAG}_other_shapes.jsonl
   python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $OUT/${TAG}_other_shapes.jsonl 2>> $OUT/${TAG}_other_shapes.err
 done
+echo "[refresh] exact fp32 against the opt-in split products: frame rate A/B in this box, error of both against an fp64 oracle"
+rm -f $OUT/${TAG}_x3_frame_ab.txt
+for i in 1 2; do for m in f32 bf16x3; do
+  python3 $ROOT/bench.py --products $m --no-cpu-baseline --no-other-configs 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('--products $m', round(d['value'], 1), 'frames/s', round(d['ms_per_step'], 4), 'ms')" >> $OUT/${TAG}_x3_frame_ab.txt
+done; done
+(cd $ROOT && python3 tools/products_error.py --out $OUT/${TAG}_products_error.json > $OUT/${TAG}_products_error.log 2>&1)
+echo "[refresh] the day-one checkpoint check on a seed-defined checkpoint (GPU step included)"
+python3 - <<PYEOF
+import sys, torch
+sys.path.insert(0, "$ROOT")
+import render_in_between_amd as rib
+from render_in_between_amd import synth
+torch.save({"state_dict": synth.make_state_dict(rib.GenSpec.from_cfg(rib.hsm_gen_config()), 0)}, "/tmp/synth_netG.pth")
+PYEOF
+(cd $ROOT && python3 tools/verify_checkpoint.py /tmp/synth_netG.pth --out /tmp/synth_gold --sizes 64 128 256 --report $OUT/${TAG}_verify_checkpoint_synthetic.json > /dev/null 2>&1) || echo "verify_checkpoint failed"
 echo "[refresh] bf16 kernel stats (config 3)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --dtype bf16 --mode chain --frames 32 --steps 10 --warmup 2 > $OUT/${TAG}_bench_bf16_prof.log 2>&1
 cp $OUT/prof_bf16/bench_kernel_stats.csv $OUT/${TAG}_bench_bf16_kernel_stats.csv
