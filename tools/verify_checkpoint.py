@@ -31,11 +31,19 @@ import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
 
-def load_checkpoint(path):
-    """PGNR/utils/utils.py:107-119: missing file -> ValueError; optional 'state_dict' wrapper; 'module.' prefixes stripped."""
+def load_checkpoint(path, trust_pickle=False):
+    """PGNR/utils/utils.py:107-119: missing file -> ValueError; optional 'state_dict' wrapper; 'module.' prefixes stripped.
+    torch.load runs with weights_only=True (tensors and plain containers only) unless --trust-pickle is given: the reference's
+    own torch.load (torch 1.4) unpickles arbitrary objects, which is only acceptable for a file whose origin is trusted."""
     if not os.path.exists(path):
         raise ValueError("No checkpoint found at {}".format(path))
-    sd = torch.load(path, map_location="cpu")
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
+    except Exception as e:      # noqa: BLE001
+        if trust_pickle:
+            raise
+        raise RuntimeError("torch.load(weights_only=True) refused the file (%s: %s); if its origin is trusted, re-run with --trust-pickle"
+                           % (type(e).__name__, " ".join(str(e).split())[:200]))
     if "state_dict" in sd and not torch.is_tensor(sd["state_dict"]):
         sd = sd["state_dict"]
     return {k.replace("module.", ""): v.detach().to(torch.float32) for k, v in sd.items()}
@@ -190,11 +198,12 @@ def main(argv=None):
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "real_ckpt"))
     ap.add_argument("--sizes", type=int, nargs="+", default=[64, 128, 256])
     ap.add_argument("--report", default=None)
+    ap.add_argument("--trust-pickle", action="store_true", help="torch.load with weights_only=False (a checkpoint that holds more than tensors and plain containers)")
     args = ap.parse_args(argv)
     report = {"checkpoint": args.checkpoint}
     ok = True
     try:
-        sd = load_checkpoint(args.checkpoint)
+        sd = load_checkpoint(args.checkpoint, args.trust_pickle)
     except Exception as e:      # noqa: BLE001
         report["load"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
         ok = False
