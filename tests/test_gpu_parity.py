@@ -1282,6 +1282,32 @@ def test_split_bf16_products_are_opt_in_and_fp32_grade():
         assert float((i1.cpu() - oi).abs().max()) <= TOL and float((m1.cpu() - om).abs().max()) <= TOL
     i2, _ = G1(label, None, fake, prev)
     assert torch.equal(i1, i2)                             # deterministic
+    # the setting belongs to the handle, not to a plan: an autoregressive segment (rib_chain, launch by launch and replayed as
+    # a captured graph) renders what the per-frame loop renders, and switching it drops the captured segments
+    T, B, H, W = 3, 2, 64, 64
+    frames = [synth.make_inputs(spec, B, H, W, 60 + t) for t in range(T)]
+    labels = torch.stack([f[0] for f in frames]).cuda(); dains = torch.stack([f[1] for f in frames]).cuda(); key = frames[0][2].cuda()
+    p_, want = key, []
+    for t in range(T):
+        p_ = G1.forward_blend(labels[t], None, dains[t], p_)[2].clone()
+        want.append(p_)
+    got = G1.chain(key, labels, dains, want_all=True)[2]
+    assert all(torch.equal(got[t], want[t]) for t in range(T))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        G1.set_graph_replay(True)
+        for k in range(4):           # (Generator.chain alternates two output sets while the option is on: two captures, then replays)
+            a = G1.chain(key, labels, dains, want_all=True)[2].clone()
+            st.synchronize()
+            assert torch.equal(a, got), k
+        assert G1.graph_stats()["replays"] >= 1
+        from render_in_between_amd import _native
+        _native.check(G1._h, _native.lib().rib_set_products(G1._h, 0))   # back to exact fp32: the captured segment must not survive
+        c = G1.chain(key, labels, dains, want_all=True)[2].clone()
+        st.synchronize()
+        _native.check(G1._h, _native.lib().rib_set_products(G1._h, 1))
+        G1.set_graph_replay(False)
+    assert not torch.equal(c, got) and float((c - got).abs().max()) <= 5e-5
     with pytest.raises(ValueError):
         rib.Generator(rib.hsm_gen_config(), compute_dtype="bf16", products="bf16x3")
 
