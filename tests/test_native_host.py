@@ -268,6 +268,33 @@ def test_unsupported_configs_fail_loudly(lib):
     assert b"multiple of 32" in lib.rib_last_error(None)
 
 
+def test_the_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under render-in-between_amd/ (the product: host mirror, driver, CLIs, C++ / HIP
+    sources) and neither bench.py's timed path nor inference.py may import, open or name it.  bench.py's one import is the
+    cpu_baseline leg, after the timed region; importing the whole product package must not pull the oracle in either."""
+    import subprocess, sys
+    pkg = os.path.join(ROOT, "render-in-between_amd")
+    hits = []
+    for dirpath, _, files in os.walk(pkg):
+        if "__pycache__" in dirpath or os.path.join("csrc", "build") in dirpath:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h", ".def", ".yaml")):
+                continue
+            text = open(os.path.join(dirpath, f), errors="replace").read()
+            for m in re.finditer(r"^\s*(from|import)\s+oracle\b|['\"/]oracle/", text, flags=re.M):
+                hits.append((os.path.relpath(os.path.join(dirpath, f), ROOT), m.group(0).strip()))
+    assert hits == [], hits
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    imports = [m.start() for m in re.finditer(r"^\s*from oracle import", bench, flags=re.M)]
+    assert len(imports) == 1 and imports[0] > bench.index("dt = time.perf_counter() - t0"), "bench.py: the oracle may only appear in the cpu_baseline leg, after the timed region"
+    code = ("import sys; sys.path.insert(0, %r); import render_in_between_amd as rib; "
+            "from render_in_between_amd import evaluator, distributed, rasterise, resize, tuning, io_worker, config, spec, synth; "
+            "from render_in_between_amd.motion import model, pose_io, spec as mspec; "
+            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')], 'the product imported the oracle'" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
 def test_generator_refuses_to_run_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
