@@ -89,9 +89,10 @@ def test_layer_taps_match_oracle_mid64():
 
 
 @pytest.mark.parametrize("name", ["mid_64", "full_64", "full_128", "full_b2_64", "full_noise_128",
-                                  "full_256", "full_320x480", "full_512"])
+                                  "full_256", "full_320x480", "full_512", "full_b3_96x160", "full_1024"])
 def test_outputs_match_reference_fixtures(name, golden_dir, golden_report):
-    """Against the outputs of the imported reference generator itself."""
+    """Against the outputs of the imported reference generator itself (round 6 added a batch-3 non-square case and the
+    1024x1024 frame of BASELINE configs[4], which had only been compared with the oracle)."""
     rep = golden_report[name]
     spec, sd, G = build("mid" if name.startswith("mid") else "full", rep["seed"])
     label, fake, prev = synth.make_inputs(spec, rep["B"], rep["H"], rep["W"], rep["seed"],

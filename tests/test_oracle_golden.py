@@ -52,7 +52,7 @@ def test_synth_checkpoint_is_deterministic_and_conditioned(golden_report):
 
 
 @pytest.mark.parametrize("name", ["full_64", "full_128", "full_b2_64", "full_noise_128",
-                                  "mid_64", "full_256", "full_320x480"])
+                                  "mid_64", "full_256", "full_320x480", "full_b3_96x160"])
 def test_oracle_matches_reference_outputs(name, golden_dir, golden_report):
     rep = golden_report[name]
     spec = rib.GenSpec.from_cfg(_cfg(name))
